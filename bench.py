@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- advance_mu_t sweeps on N MI355X, one JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one advance_mu_t sweep (one acoustic sub-step's call) over the whole
+4096 x 60 x 4096 fp64 domain (BASELINE.json configs[2]/[3]); inputs are resident in HBM before
+the timed region.  With N > 1 the SAME domain is split into N j-slabs (strong scaling), each
+rank trades its one-row input halos over RCCL send/recv every sweep
+(wrf-model-cuda-sample_amd/patch.py) while its interior rows compute.
+
+Output keys beyond the driver's contract:
+  roofline      algorithmic HBM bytes of one sweep (W*NI*NJ*(11*NK+14))
+                divided by the HIP-event time of the kernel launches, against 8 TB/s per GPU
+  cpu_baseline  the CPU oracle (oracle/, a C port of the Fortran), j-tiled over the host
+                cores, timed on a bounded j-slab sample of the same synthetic domain (rank 0, N=1)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ni", type=int, default=4096)
+    ap.add_argument("--nk", type=int, default=60)
+    ap.add_argument("--nj", type=int, default=4096)
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 column, 2 march")
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-overlap", action="store_true", help="exchange halos before computing (no 2nd stream)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=64, help="j rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(ni, nk, nj, itemsize):
+    """Compulsory HBM traffic of one sweep (SURVEY.md section 8a / BASELINE.md section 3)."""
+    return itemsize * ni * nj * (11 * nk + 14)
+
+
+def verify_first_sweep(pkg, oracle, dev, gb, dims, dtype, seed, rank_rows):
+    """After exactly one sweep from fresh inputs: recompute a few 3-row j-slabs with the oracle
+    from regenerated inputs and compare bit for bit (size-independent parity check)."""
+    S = pkg.synth
+    b = dev.bounds
+    jlo_own, jhi_own = rank_rows
+    cand = sorted({jlo_own, max(jlo_own, jhi_own - 2), (jlo_own + jhi_own) // 2})
+    for jlo in cand:
+        jhi = min(jlo + 2, jhi_own)
+        sb = gb.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
+        want = S.make_patch(sb, dev.config, dtype=dtype, seed=seed, global_dims=dims)
+        oracle.advance_mu_t_omp(*want.args(), nthreads=min(3, jhi - jlo + 1))
+        for n in S.OUTPUTS:
+            got = dev.arrays[n][jlo - b.jms: jhi + 1 - b.jms].cpu().numpy()
+            w = want.arrays[n][1: 1 + (jhi - jlo + 1)]
+            if not np.array_equal(got.view(np.uint8), w.view(np.uint8)):
+                return False, f"rows {jlo}..{jhi} of {n} differ from the oracle"
+    return True, ""
+
+
+def cpu_baseline(pkg, oracle, dims, dtype, seed, rows, seconds):
+    """Oracle (C port of the Fortran), j-tiled over all host cores, on a j-slab sample."""
+    S = pkg.synth
+    ni, nk, nj = dims
+    rows = max(1, min(rows, nj))
+    gb = S.domain_bounds(ni, nk, nj)
+    jlo = max(1, nj // 2 - rows // 2)
+    sb = gb.replace(jms=jlo - 1, jme=jlo + rows, jts=jlo, jte=jlo + rows - 1)
+    p = S.make_patch(sb, pkg.GridConfig(), dtype=dtype, seed=seed, global_dims=dims)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(cores, rows))
+    oracle.advance_mu_t_omp(*p.args(), nthreads=threads)           # warm
+    times = []
+    t_end = time.perf_counter() + seconds
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 200):
+        t0 = time.perf_counter()
+        oracle.advance_mu_t_omp(*p.args(), nthreads=threads)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    cells = ni * nk * rows
+    return {"value": round(cells / med / 1e6, 2), "unit": "Mcells/s", "cores": threads, "kind": "port",
+            "sample": f"{ni}x{nk}x{rows} j-slab of the same synthetic domain, median of {len(times)} sweeps, "
+                      f"gcc -O2 OpenMP j-tiles ({threads} threads)",
+            "ms_per_sweep_sample": round(med * 1e3, 3)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    pkg = g.load_package()
+    S = pkg.synth
+    dtype = np.float64 if a.dtype == "f64" else np.float32
+    itemsize = np.dtype(dtype).itemsize
+    dims = (a.ni, a.nk, a.nj)
+    gb = S.domain_bounds(*dims, aligned=True)
+    sb = S.slab_bounds(gb, rank, world)
+    cfg = pkg.GridConfig()
+
+    dev = S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device=device)
+    if world > 1:
+        # poison the halo rows so that only a working exchange gives the right answer
+        for name in S.HALO_FROM_ABOVE:
+            if rank < world - 1:
+                dev.arrays[name][-1].fill_(float("nan"))
+        if rank > 0:
+            dev.arrays["t_1"][0].fill_(float("nan"))
+    stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap,
+                                    variant=a.variant)
+    torch.cuda.synchronize()
+
+    verified, why = None, ""
+    oracle = None
+    warm_done = 0
+    if a.warmup > 0 and not a.no_verify:
+        oracle = g.load_oracle()
+        stepper.step()
+        warm_done = 1
+        torch.cuda.synchronize()
+        verified, why = verify_first_sweep(pkg, oracle, dev, gb, dims, dtype, a.seed, (sb.jts, sb.jte))
+    for _ in range(a.warmup - warm_done):
+        stepper.step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        stepper.step()
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+
+    if world > 1:
+        t = torch.tensor([wall, ev_ms, 1.0 if verified in (None, True) else 0.0], device=device, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = t.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        wall, ev_ms = float(tmax[0]), float(tmax[1])
+        if verified is not None:
+            verified = bool(tmin[2] > 0.5)
+
+    if rank == 0:
+        cells = a.ni * a.nk * a.nj
+        ms_per_step = wall * 1e3 / max(a.steps, 1)
+        value = cells * a.steps / wall / 1e6
+        ev_per_step_s = ev_ms * 1e-3 / max(a.steps, 1)
+        abytes = algorithmic_bytes(a.ni, a.nk, a.nj, itemsize)
+        achieved = abytes / world / ev_per_step_s / 1e9              # GB/s per GPU (slowest rank)
+        traffic = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists():
+            try:
+                rec = json.loads(tf.read_text()).get(f"{a.ni}x{a.nk}x{a.nj}_{a.dtype}_n{world}")
+                if rec:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "advance_mu_t grid-cells/sec (Mcells/s) + achieved HBM GB/s",
+            "value": round(value, 2),
+            "unit": "Mcells/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": a.dtype,
+            "data": "synthetic (seeded closed-form WRF-shaped fields, include/amt_synth.h)",
+            "config": {"workload": f"advance_mu_t {a.ni}x{a.nk}x{a.nj} (i,k,j) {a.dtype}, "
+                                   f"{world} j-slab(s), one-row RCCL halo exchange per sweep",
+                       "ni": a.ni, "nk": a.nk, "nj": a.nj, "variant": a.variant,
+                       "halo_overlap": (not a.no_overlap) if world > 1 else None,
+                       "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep()},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": abytes // world,
+                         "kernel_ms_per_launch": round(ev_per_step_s * 1e3, 4),
+                         "aggregate_GBps": round(abytes / ev_per_step_s / 1e9, 1)},
+            "verified_vs_oracle": verified,
+        }
+        if why:
+            out["verify_message"] = why
+        if world == 1 and not a.no_cpu_baseline:
+            oracle = oracle or g.load_oracle()
+            out["cpu_baseline"] = cpu_baseline(pkg, oracle, dims, dtype, a.seed, a.cpu_rows, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if verified is False:
+        raise SystemExit(3)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+/*
+ * include/amt_advance_mu_t.h -- C-ABI of the MI355X (gfx950) advance_mu_t path.
+ *
+ * Drop-in boundary for WRF-ARW's acoustic-substep routine
+ *   SUBROUTINE advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu,
+ *                           muv, mudf, t, t_1, t_ave, ft, mu_tend, rdx, rdy, dts,
+ *                           epssm, dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx,
+ *                           msfty, config_flags, ids,ide, jds,jde, kde, ims,ime,
+ *                           jms,jme, kms,kme, its,ite, jts,jte, kts,kte)
+ * (reference: module_small_step_em.f90:7-18; C/CUDA precedent for a flat C
+ * signature: advance_mu_t.h:10-23, advance_mu_t_cu.h:3-17).
+ *
+ * Conventions shared by every entry point
+ *  - Argument ORDER is the Fortran one.  config_flags is replaced by the three
+ *    logicals the routine reads (module_small_step_em.f90:97-103; the C struct
+ *    of advance_mu_t.h:3-8 carries the same three) as int 0/1, in the order
+ *    periodic_x, specified, nested.
+ *  - All 17 bounds are Fortran-style INCLUSIVE indices passed unchanged; there
+ *    is no kds (the Fortran signature has none).  Arrays are i-fastest:
+ *    element (i,k,j) of a 3-D array is at ((j-jms)*kdim + (k-kms))*idim + (i-ims),
+ *    (i,j) of a 2-D array at (j-jms)*idim + (i-ims), (k) of a 1-D array at k-kms,
+ *    with idim = ime-ims+1, kdim = kme-kms+1  (advance_mu_t.c:8-9,33-55).
+ *  - Preconditions (anything else is undefined in the Fortran as well, see
+ *    DESIGN.md): kts == 1, kte == kde, kms <= 1, kme >= kte, and the compute
+ *    window plus its one-cell input halo (i-1, i+1, j-1, j+1) inside memory.
+ *  - Return value: AMT_OK or an amt_status code; nothing ever calls exit()
+ *    (the reference's wrapper prints and exit(1)s, advance_mu_t_no_async.cu:22-32,
+ *    82-85).  amt_last_error() gives the text for the calling thread.
+ *  - Outputs outside the compute window, and level k = kte, keep the caller's
+ *    contents (the reference uploads its OUT arrays for the same reason,
+ *    advance_mu_t_no_async.cu:259,270-272).
+ *  - Calls on the same stream/handle are not re-entrant; different streams are
+ *    independent.
+ *
+ * There is no CPU fallback anywhere behind this header: without a HIP device
+ * every compute entry point returns AMT_ERR_NO_DEVICE / AMT_ERR_HIP.
+ */
+#ifndef AMT_ADVANCE_MU_T_H
+#define AMT_ADVANCE_MU_T_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum amt_status {
+    AMT_OK = 0,
+    AMT_ERR_HIP = 1,           /* a HIP runtime call failed (text in amt_last_error) */
+    AMT_ERR_PRECONDITION = 2,  /* bounds violate the preconditions above            */
+    AMT_ERR_INVALID_ARG = 3,   /* null pointer, bad dtype / field id / variant      */
+    AMT_ERR_NO_DEVICE = 4,     /* no gfx950 device visible                          */
+    AMT_ERR_ALLOC = 5          /* device or host allocation failed                  */
+} amt_status;
+
+/* Kernel variants (amt_set_variant / `variant` arguments).  AMT_VARIANT_AUTO picks
+ * the fastest one that supports the given shape. */
+enum amt_variant {
+    AMT_VARIANT_AUTO = 0,
+    AMT_VARIANT_COLUMN = 1,    /* one lane per (i,j) column, k-column staged in LDS */
+    AMT_VARIANT_MARCH = 2      /* (i,k)-cell lanes marching in j, k-chains through LDS */
+};
+
+const char *amt_version(void);
+const char *amt_status_string(int status);
+const char *amt_last_error(void);
+int amt_device_count(void);               /* number of visible HIP devices, 0 if none */
+
+/* ------------------------------------------------------------------------
+ * (1) One-shot drop-ins: HOST arrays in, HOST arrays out.  Replaces the body of
+ *     the Fortran routine (module_small_step_em.f90:7-252) and the CUDA host
+ *     wrapper (advance_mu_t_no_async.cu:35-424): allocate, upload, launch,
+ *     download, free -- on the current HIP device.
+ * ------------------------------------------------------------------------ */
+int amt_advance_mu_t_f32(
+    float *ww, const float *ww_1, const float *u, const float *u_1,
+    const float *v, const float *v_1,
+    float *mu, const float *mut, float *muave, float *muts,
+    const float *muu, const float *muv,
+    float *mudf, float *t, const float *t_1,
+    float *t_ave, const float *ft, const float *mu_tend,
+    float rdx, float rdy, float dts, float epssm,
+    const float *dnw, const float *fnm, const float *fnp, const float *rdnw,
+    const float *msfuy, const float *msfvx_inv,
+    const float *msftx, const float *msfty,
+    int periodic_x, int specified, int nested,
+    int ids, int ide, int jds, int jde, int kde,
+    int ims, int ime, int jms, int jme, int kms, int kme,
+    int its, int ite, int jts, int jte, int kts, int kte);
+
+int amt_advance_mu_t_f64(
+    double *ww, const double *ww_1, const double *u, const double *u_1,
+    const double *v, const double *v_1,
+    double *mu, const double *mut, double *muave, double *muts,
+    const double *muu, const double *muv,
+    double *mudf, double *t, const double *t_1,
+    double *t_ave, const double *ft, const double *mu_tend,
+    double rdx, double rdy, double dts, double epssm,
+    const double *dnw, const double *fnm, const double *fnp, const double *rdnw,
+    const double *msfuy, const double *msfvx_inv,
+    const double *msftx, const double *msfty,
+    int periodic_x, int specified, int nested,
+    int ids, int ide, int jds, int jde, int kde,
+    int ims, int ime, int jms, int jme, int kms, int kme,
+    int its, int ite, int jts, int jte, int kts, int kte);
+
+/* ------------------------------------------------------------------------
+ * (2) Device-resident drop-ins: the same call with every array pointer in
+ *     DEVICE memory of the current device, enqueued on `hip_stream`
+ *     (a hipStream_t; NULL = the default stream) and returning without
+ *     synchronising.  This is the kernel-only boundary the reference times
+ *     (advance_mu_t_no_async.cu:324-363) and what a resident small-step loop
+ *     (solve_em) or a j-slab owner calls per sub-step; a slab owner passes the
+ *     GLOBAL ids..jde and its LOCAL jms..jme / jts..jte, exactly as a WRF patch
+ *     does.  `variant` is an amt_variant.
+ * ------------------------------------------------------------------------ */
+int amt_advance_mu_t_device_f32(
+    void *hip_stream, int variant,
+    float *ww, const float *ww_1, const float *u, const float *u_1,
+    const float *v, const float *v_1,
+    float *mu, const float *mut, float *muave, float *muts,
+    const float *muu, const float *muv,
+    float *mudf, float *t, const float *t_1,
+    float *t_ave, const float *ft, const float *mu_tend,
+    float rdx, float rdy, float dts, float epssm,
+    const float *dnw, const float *fnm, const float *fnp, const float *rdnw,
+    const float *msfuy, const float *msfvx_inv,
+    const float *msftx, const float *msfty,
+    int periodic_x, int specified, int nested,
+    int ids, int ide, int jds, int jde, int kde,
+    int ims, int ime, int jms, int jme, int kms, int kme,
+    int its, int ite, int jts, int jte, int kts, int kte);
+
+int amt_advance_mu_t_device_f64(
+    void *hip_stream, int variant,
+    double *ww, const double *ww_1, const double *u, const double *u_1,
+    const double *v, const double *v_1,
+    double *mu, const double *mut, double *muave, double *muts,
+    const double *muu, const double *muv,
+    double *mudf, double *t, const double *t_1,
+    double *t_ave, const double *ft, const double *mu_tend,
+    double rdx, double rdy, double dts, double epssm,
+    const double *dnw, const double *fnm, const double *fnp, const double *rdnw,
+    const double *msfuy, const double *msfvx_inv,
+    const double *msftx, const double *msfty,
+    int periodic_x, int specified, int nested,
+    int ids, int ide, int jds, int jde, int kde,
+    int ims, int ime, int jms, int jme, int kms, int kme,
+    int its, int ite, int jts, int jte, int kts, int kte);
+
+/* Compute window the routine will update for the given flags and bounds
+ * (module_small_step_em.f90:91-106).  Pure host arithmetic, no device needed. */
+int amt_compute_window(int periodic_x, int specified, int nested,
+                       int ids, int ide, int jds, int jde,
+                       int its, int ite, int jts, int jte, int kts, int kte,
+                       int *i_start, int *i_end, int *j_start, int *j_end,
+                       int *k_start, int *k_end);
+
+/* ------------------------------------------------------------------------
+ * (3) Resident domain handle: owns the 26 device arrays of one patch
+ *     (memory extents ims:ime, kms:kme, jms:jme), a compute stream and the four
+ *     scalars.  For C / Fortran hosts that keep ww, t, mu on the GPU across
+ *     sub-steps; dtype_bytes is 4 (float) or 8 (double).  Field ids are
+ *     enum amt_field of amt_synth.h (the Fortran argument order).
+ * ------------------------------------------------------------------------ */
+typedef struct amt_domain amt_domain;
+
+int amt_domain_create(amt_domain **out, int dtype_bytes,
+                      int periodic_x, int specified, int nested,
+                      int ids, int ide, int jds, int jde, int kde,
+                      int ims, int ime, int jms, int jme, int kms, int kme,
+                      int its, int ite, int jts, int jte, int kts, int kte);
+int amt_domain_destroy(amt_domain *d);
+int amt_domain_set_scalars(amt_domain *d, double rdx, double rdy, double dts, double epssm);
+int amt_domain_set_variant(amt_domain *d, int variant);
+/* whole-array copies in the (ims:ime[,kms:kme][,jms:jme]) layout; synchronous */
+int amt_domain_upload(amt_domain *d, int field, const void *host);
+int amt_domain_download(amt_domain *d, int field, void *host);
+/* fill every field from amt_synth.h; (gi0,gk0,gj0) = GLOBAL zero-based index of this
+ * patch's element (ims,kms,jms); (gidim,gkdim,gjdim) = GLOBAL memory extents */
+int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,
+                              long gi0, long gk0, long gj0,
+                              long gidim, long gkdim, long gjdim);
+/* enqueue n_sweeps calls of advance_mu_t over the patch's tile; asynchronous */
+int amt_domain_step(amt_domain *d, int n_sweeps);
+/* same, bracketed by HIP events on the domain's stream; returns after completion */
+int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_total);
+int amt_domain_sync(amt_domain *d);
+void *amt_domain_field_ptr(amt_domain *d, int field);   /* device pointer, NULL on error */
+void *amt_domain_stream(amt_domain *d);                 /* hipStream_t */
+
+/* ------------------------------------------------------------------------
+ * (4) Synthetic inputs (amt_synth.h) for a patch of extents idim x kdim x jdim
+ *     whose element (0,0,0) is GLOBAL (gi0,gk0,gj0).  Rank-2 fields ignore the k
+ *     arguments, rank-1 fields the i and j arguments.  The host and the device
+ *     version produce identical bits.
+ * ------------------------------------------------------------------------ */
+int amt_synth_fill_host(int field, int dtype_bytes, void *dst, uint64_t seed,
+                        long idim, long kdim, long jdim,
+                        long gi0, long gk0, long gj0,
+                        long gidim, long gkdim, long gjdim);
+int amt_synth_fill_device(void *hip_stream, int field, int dtype_bytes, void *dst_device,
+                          uint64_t seed,
+                          long idim, long kdim, long jdim,
+                          long gi0, long gk0, long gj0,
+                          long gidim, long gkdim, long gjdim);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* AMT_ADVANCE_MU_T_H */

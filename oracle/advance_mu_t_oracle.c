@@ -1,0 +1,36 @@
+/*
+ * oracle/advance_mu_t_oracle.c
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the CPU oracle for the advance_mu_t hot
+ * path: a plain-C restatement of the reference Fortran
+ * (/root/reference/module_small_step_em.f90:7-252).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * product library (wrf-model-cuda-sample_amd/csrc) never links, imports or calls
+ * it and has no CPU fallback.
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks this
+ * restatement bit-for-bit against the reference Fortran itself, compiled from
+ * the sources where they lie into oracle/_ref/ (see oracle/Makefile), and
+ * tests/golden/ holds outputs of that compiled reference on seeded synthetic
+ * inputs (the reference ships no golden vectors of its own: its drivers diff
+ * against /data2/... dumps that are not in the repository).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
+ */
+#include <stddef.h>
+#include <stdlib.h>
+
+#define ORACLE_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define ORACLE_MAX(a, b) ((a) > (b) ? (a) : (b))
+
+#define REAL float
+#define ORACLE_FN(name) name##_f32
+#include "advance_mu_t_oracle_impl.h"
+#undef REAL
+#undef ORACLE_FN
+
+#define REAL double
+#define ORACLE_FN(name) name##_f64
+#include "advance_mu_t_oracle_impl.h"
+#undef REAL
+#undef ORACLE_FN

@@ -1,0 +1,162 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front end of the CPU checker for the advance_mu_t path:
+
+* ``advance_mu_t(...)``      -- the plain-C restatement (oracle/advance_mu_t_oracle.c,
+  restating /root/reference/module_small_step_em.f90:7-252), same argument list as
+  the Fortran routine, numpy arrays updated in place.
+* ``advance_mu_t_omp(...)``  -- the same, j-tiled over host threads (the scheme
+  sketched in advance_mu_t_driver.f90:175-209); timed by bench.py's cpu_baseline leg.
+* ``ref_advance_mu_t(...)``  -- the REFERENCE Fortran itself (oracle/_ref/, built by
+  ``make -C oracle ref`` from the sources under /root/reference; exists only where
+  that build has run).  Used to pin the restatement and to generate tests/golden/.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product package never does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "liboracle_amt.so"
+REF_PATHS = {4: HERE / "_ref" / "libref_amt_f32.so", 8: HERE / "_ref" / "libref_amt_f64.so"}
+
+# the five dump files the reference writes into the cwd on every call
+# (module_small_step_em.f90:175-189)
+_REF_DUMPS = ("muave_before_theta.bin", "mu_before_theta.bin", "mudf_before_theta.bin",
+              "muts_before_theta.bin", "ww_before_theta.bin")
+
+# positions in the Fortran argument list
+ARRAY_NAMES_A = ("ww", "ww_1", "u", "u_1", "v", "v_1", "mu", "mut", "muave", "muts", "muu", "muv",
+                 "mudf", "t", "t_1", "t_ave", "ft", "mu_tend")
+SCALAR_NAMES = ("rdx", "rdy", "dts", "epssm")
+ARRAY_NAMES_B = ("dnw", "fnm", "fnp", "rdnw", "msfuy", "msfvx_inv", "msftx", "msfty")
+INT_NAMES = ("ids", "ide", "jds", "jde", "kde", "ims", "ime", "jms", "jme", "kms", "kme",
+             "its", "ite", "jts", "jte", "kts", "kte")
+
+
+def build(ref: bool | None = None) -> None:
+    """Compile the C restatement, and the reference build when its sources exist."""
+    subprocess.run(["make", "-C", str(HERE), "all"], check=True, capture_output=True)
+    if ref is None:
+        ref = Path("/root/reference/module_small_step_em.f90").exists()
+    if ref:
+        subprocess.run(["make", "-C", str(HERE), "ref"], check=True, capture_output=True)
+
+
+_lib = None
+_ref_libs: dict[int, ctypes.CDLL] = {}
+
+
+def _sig(real, extra_int=0):
+    p = ctypes.c_void_p
+    return [p] * 18 + [real] * 4 + [p] * 8 + [ctypes.c_int] * (3 + 17 + extra_int)
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build(ref=False)
+        L = ctypes.CDLL(str(LIB_PATH))
+        for suffix, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
+            f = getattr(L, f"oracle_advance_mu_t_{suffix}")
+            f.argtypes, f.restype = _sig(real), ctypes.c_int
+            g = getattr(L, f"oracle_advance_mu_t_omp_{suffix}")
+            g.argtypes, g.restype = _sig(real, 1), ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def have_ref(itemsize: int = 8) -> bool:
+    return REF_PATHS[itemsize].exists()
+
+
+def _ref_lib(itemsize: int) -> ctypes.CDLL:
+    if itemsize not in _ref_libs:
+        real = ctypes.c_float if itemsize == 4 else ctypes.c_double
+        L = ctypes.CDLL(str(REF_PATHS[itemsize]))
+        L.ref_advance_mu_t.argtypes, L.ref_advance_mu_t.restype = _sig(real), None
+        _ref_libs[itemsize] = L
+    return _ref_libs[itemsize]
+
+
+def _flags(config_flags):
+    """config_flags: object with .periodic_x/.specified/.nested, or a mapping, or a 3-tuple
+    in the order (periodic_x, specified, nested)."""
+    if isinstance(config_flags, (tuple, list)):
+        px, sp, ne = config_flags
+    elif isinstance(config_flags, dict):
+        px, sp, ne = (config_flags.get(k, False) for k in ("periodic_x", "specified", "nested"))
+    else:
+        px, sp, ne = config_flags.periodic_x, config_flags.specified, config_flags.nested
+    return int(bool(px)), int(bool(sp)), int(bool(ne))
+
+
+def _marshal(arrays_a, scalars, arrays_b, config_flags, ints):
+    dt = arrays_a[0].dtype
+    if dt not in (np.float32, np.float64):
+        raise TypeError(f"unsupported dtype {dt}")
+    for a in tuple(arrays_a) + tuple(arrays_b):
+        if not isinstance(a, np.ndarray) or a.dtype != dt or not a.flags["F_CONTIGUOUS"] and not a.flags["C_CONTIGUOUS"]:
+            raise TypeError("all arrays must be contiguous numpy arrays of one dtype")
+    real = ctypes.c_float if dt == np.float32 else ctypes.c_double
+    args = [a.ctypes.data_as(ctypes.c_void_p) for a in arrays_a]
+    args += [real(float(s)) for s in scalars]
+    args += [a.ctypes.data_as(ctypes.c_void_p) for a in arrays_b]
+    args += list(_flags(config_flags)) + [int(x) for x in ints]
+    return dt, args
+
+
+def advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
+                 t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,
+                 msfuy, msfvx_inv, msftx, msfty, config_flags,
+                 ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme,
+                 its, ite, jts, jte, kts, kte, nthreads: int | None = None):
+    """CPU restatement; argument list of module_small_step_em.f90:7-18.  Arrays are numpy,
+    laid out i-fastest (shape (jdim,kdim,idim) C-order or (idim,kdim,jdim) F-order)."""
+    dt, args = _marshal((ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
+                         t_ave, ft, mu_tend), (rdx, rdy, dts, epssm),
+                        (dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty), config_flags,
+                        (ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte))
+    sfx = "f32" if dt == np.float32 else "f64"
+    if nthreads is None:
+        rc = getattr(lib(), f"oracle_advance_mu_t_{sfx}")(*args)
+    else:
+        rc = getattr(lib(), f"oracle_advance_mu_t_omp_{sfx}")(*args, int(nthreads))
+    if rc:
+        raise ValueError(f"oracle_advance_mu_t: status {rc} (2 = bounds outside what the Fortran defines)")
+
+
+def advance_mu_t_omp(*args, nthreads: int):
+    return advance_mu_t(*args, nthreads=nthreads)
+
+
+def ref_advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
+                     t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,
+                     msfuy, msfvx_inv, msftx, msfty, config_flags,
+                     ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme,
+                     its, ite, jts, jte, kts, kte):
+    """The reference Fortran routine itself (oracle/_ref).  Runs inside a scratch cwd whose
+    five dump-file names point at /dev/null."""
+    dt, args = _marshal((ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
+                         t_ave, ft, mu_tend), (rdx, rdy, dts, epssm),
+                        (dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty), config_flags,
+                        (ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte))
+    L = _ref_lib(dt.itemsize)
+    old = os.getcwd()
+    with tempfile.TemporaryDirectory(prefix="amt_ref_") as scratch:
+        for name in _REF_DUMPS:
+            os.symlink("/dev/null", os.path.join(scratch, name))
+        os.chdir(scratch)
+        try:
+            L.ref_advance_mu_t(*args)
+        finally:
+            os.chdir(old)

@@ -1,0 +1,46 @@
+"""pytest configuration: the `gpu` marker and shared loaders."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+if str(ROOT / "tests") not in sys.path:
+    sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def entry():
+    import __graft_entry__ as g
+    return g
+
+
+@pytest.fixture(scope="session")
+def pkg(entry):
+    """The product package (HIP library behind the C-ABI).  Built on demand."""
+    from pathlib import Path as _P
+    p = entry.PKG_DIR / "libamt_advance_mu_t.so"
+    if not p.exists():
+        entry.build()
+    return entry.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle(entry):
+    """TEST INFRASTRUCTURE: the CPU checker (oracle/)."""
+    o = entry.load_oracle()
+    o.lib()
+    return o
+
+
+def bits_equal(a, b) -> bool:
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))

@@ -1,0 +1,105 @@
+"""N > 1 path on CPU: world_size 2 and 3 over gloo.  The j-slab decomposition + one-row
+input-halo exchange (wrf-model-cuda-sample_amd/patch.py, the code bench.py runs over RCCL)
+must reproduce the unsplit domain bit for bit.  The compute callable is injected: here it
+is the oracle (tests only); the product passes the HIP entry point."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, shape, flags, sweeps, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as g
+        pkg, oracle = g.load_package(), g.load_oracle()
+        S = pkg.synth
+        ni, nk, nj = shape
+        gb = S.domain_bounds(ni, nk, nj)
+        sb = S.slab_bounds(gb, rank, world)
+        host = S.make_patch(sb, pkg.GridConfig(**flags), seed=77, global_dims=shape)
+        arrays = {k: torch.from_numpy(v) for k, v in host.arrays.items()}
+        # poison the halo rows: only a correct exchange can make the result right
+        for name in S.HALO_FROM_ABOVE:
+            if rank < world - 1:
+                arrays[name][-1].fill_(float("nan"))
+        if rank > 0:
+            arrays["t_1"][0].fill_(float("nan"))
+        patch = S.Patch(sb, host.config, arrays, host.rdx, host.rdy, host.dts, host.epssm, shape)
+
+        def compute(*args):
+            args = [a.numpy() if isinstance(a, torch.Tensor) else a for a in args]
+            oracle.advance_mu_t(*args)
+
+        stepper = pkg.patch.SlabStepper(patch, rank, world, compute)
+        for _ in range(sweeps):
+            stepper.step()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), jms=sb.jms, jts=sb.jts, jte=sb.jte,
+                 halo_bytes=stepper.halo_bytes_per_sweep(),
+                 **{n: arrays[n].numpy() for n in S.OUTPUTS})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,flags", [
+    (2, (33, 7, 10), dict()),
+    (2, (20, 5, 9), dict(specified=True)),
+    (3, (18, 4, 7), dict(nested=True)),      # middle slab has two neighbours; a 2-row slab
+    (3, (12, 3, 3), dict()),                 # one-row slabs
+])
+def test_slabs_reproduce_the_unsplit_domain(tmp_path, world, shape, flags):
+    sweeps = 2
+    mp.spawn(_worker, args=(world, _free_port(), shape, flags, sweeps, str(tmp_path)), nprocs=world, join=True)
+
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as g
+    pkg, oracle = g.load_package(), g.load_oracle()
+    S = pkg.synth
+    full = S.make_patch(S.domain_bounds(*shape), pkg.GridConfig(**flags), seed=77)
+    for _ in range(sweeps):
+        oracle.advance_mu_t(*full.args())
+    total_halo = 0
+    for rank in range(world):
+        r = np.load(tmp_path / f"rank{rank}.npz")
+        jms, jts, jte = int(r["jms"]), int(r["jts"]), int(r["jte"])
+        total_halo += int(r["halo_bytes"])
+        for n in S.OUTPUTS:
+            mine = r[n][jts - jms: jte - jms + 1]
+            want = full.arrays[n][jts: jte + 1]          # global jms = 0
+            assert np.array_equal(mine.view(np.uint8), want.view(np.uint8)), (rank, n)
+    ni, nk, _ = shape
+    idim, kdim = ni + 2, nk + 1
+    per_interface = 8 * (idim * kdim * 4 + idim * 2)     # W*idim*kdim*4 + W*idim*2
+    assert total_halo == 2 * (world - 1) * per_interface  # counted on both sides of each interface
+
+
+def test_slab_bounds_partition_the_rows(pkg):
+    S = pkg.synth
+    g = S.domain_bounds(8, 3, 37)
+    rows = []
+    for r in range(5):
+        b = S.slab_bounds(g, r, 5)
+        assert (b.jms, b.jme) == (b.jts - 1, b.jte + 1)
+        assert (b.ids, b.ide, b.jds, b.jde) == (g.ids, g.ide, g.jds, g.jde)
+        rows += list(range(b.jts, b.jte + 1))
+    assert rows == list(range(1, 38))
+    with pytest.raises(ValueError):
+        S.slab_bounds(S.domain_bounds(8, 3, 2), 0, 3)

@@ -1,0 +1,87 @@
+"""advance_mu_t -- Python mirror of the reference routine's interface.
+
+Same name, argument order and meaning as ``SUBROUTINE advance_mu_t``
+(module_small_step_em.f90:7-18); ``config_flags`` is anything with
+``.periodic_x/.specified/.nested`` (``GridConfig``).  Arrays are updated in place.
+
+* numpy arrays  -> one-shot host drop-in  ``amt_advance_mu_t_f32/_f64``
+* torch CUDA tensors -> device-resident drop-in ``amt_advance_mu_t_device_f32/_f64`` on
+  ``stream`` (default: torch's current stream), asynchronous.
+
+Arrays are i-fastest: a 3-D field is a C-contiguous array of shape (jdim, kdim, idim)
+(= Fortran (ims:ime, kms:kme, jms:jme)), a 2-D field (jdim, idim), a 1-D field (kdim,).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import lib as _lib
+from .config import flags_as_ints
+
+VARIANT_AUTO, VARIANT_COLUMN, VARIANT_MARCH = 0, 1, 2
+
+
+def compute_window(config_flags, ids, ide, jds, jde, its, ite, jts, jte, kts, kte):
+    """(i_start, i_end, j_start, j_end, k_start, k_end) of module_small_step_em.f90:91-106."""
+    L = _lib.load_library()
+    out = [ctypes.c_int() for _ in range(6)]
+    _lib.check(L.amt_compute_window(*flags_as_ints(config_flags), ids, ide, jds, jde,
+                                    its, ite, jts, jte, kts, kte, *[ctypes.byref(o) for o in out]))
+    return tuple(o.value for o in out)
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
+                 t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,
+                 msfuy, msfvx_inv, msftx, msfty, config_flags,
+                 ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme,
+                 its, ite, jts, jte, kts, kte, *, stream=None, variant=VARIANT_AUTO):
+    L = _lib.load_library()
+    arrays_a = (ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1, t_ave, ft, mu_tend)
+    arrays_b = (dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty)
+    ints = [int(x) for x in (ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte)]
+    idim, kdim, jdim = ime - ims + 1, kme - kms + 1, jme - jms + 1
+    rank3 = {0, 1, 2, 3, 4, 5, 13, 14, 15, 16}
+    want = [(jdim * kdim * idim) if n in rank3 else (jdim * idim) for n in range(18)]
+    want += [kdim] * 4 + [jdim * idim] * 4
+    flags = list(flags_as_ints(config_flags))
+
+    if _is_torch(ww):
+        import torch
+        dt = ww.dtype
+        if dt not in (torch.float32, torch.float64):
+            raise TypeError(f"unsupported dtype {dt}")
+        for a, n in zip(arrays_a + arrays_b, want):
+            if not (_is_torch(a) and a.is_cuda and a.dtype == dt and a.is_contiguous() and a.numel() == n):
+                raise TypeError("device call needs contiguous CUDA tensors of one dtype and of the memory extents")
+        real = ctypes.c_float if dt == torch.float32 else ctypes.c_double
+        if stream is None:
+            stream = torch.cuda.current_stream(ww.device)
+        handle = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+        fn = L.amt_advance_mu_t_device_f32 if dt == torch.float32 else L.amt_advance_mu_t_device_f64
+        with torch.cuda.device(ww.device):
+            status = fn(ctypes.c_void_p(handle), int(variant),
+                        *[ctypes.c_void_p(a.data_ptr()) for a in arrays_a],
+                        *[real(float(s)) for s in (rdx, rdy, dts, epssm)],
+                        *[ctypes.c_void_p(a.data_ptr()) for a in arrays_b], *flags, *ints)
+        _lib.check(status)
+        return
+
+    dt = ww.dtype
+    if dt not in (np.float32, np.float64):
+        raise TypeError(f"unsupported dtype {dt}")
+    for a, n in zip(arrays_a + arrays_b, want):
+        if not (isinstance(a, np.ndarray) and a.dtype == dt and a.size == n
+                and (a.flags["C_CONTIGUOUS"] or a.flags["F_CONTIGUOUS"])):
+            raise TypeError("host call needs contiguous numpy arrays of one dtype and of the memory extents")
+    real = ctypes.c_float if dt == np.float32 else ctypes.c_double
+    fn = L.amt_advance_mu_t_f32 if dt == np.float32 else L.amt_advance_mu_t_f64
+    status = fn(*[a.ctypes.data_as(ctypes.c_void_p) for a in arrays_a],
+                *[real(float(s)) for s in (rdx, rdy, dts, epssm)],
+                *[a.ctypes.data_as(ctypes.c_void_p) for a in arrays_b], *flags, *ints)
+    _lib.check(status)

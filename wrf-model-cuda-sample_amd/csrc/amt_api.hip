@@ -1,0 +1,581 @@
+// amt_api.hip -- the C-ABI of include/amt_advance_mu_t.h on top of the gfx950 kernels.
+//
+// Host-side runtime of the path: bound checking and index normalisation
+// (the job of advance_mu_t_no_async.cu:57-85 in the reference), the one-shot
+// host-array drop-in (advance_mu_t_no_async.cu:178-423: alloc, H2D, launch, D2H,
+// free), the device-resident drop-in, the resident domain handle and the
+// synthetic-input fill.  There is deliberately no CPU compute path in this file.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <new>
+
+#include "../../include/amt_advance_mu_t.h"
+#include "../../include/amt_synth.h"
+#include "amt_params.h"
+
+template <typename T> hipError_t amt_launch_column(hipStream_t, const AmtParams<T> &);
+template <typename T> hipError_t amt_launch_march(hipStream_t, const AmtParams<T> &);
+template <typename T> bool amt_march_supported(const AmtParams<T> &);
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int amt_fail(int status, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+#define AMT_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return amt_fail(e_ == hipErrorNoDevice ? AMT_ERR_NO_DEVICE : AMT_ERR_HIP,   \
+                            "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                            __FILE__, __LINE__);                                        \
+    } while (0)
+
+extern "C" const char *amt_version(void) { return "amt-advance_mu_t 0.1 (gfx950)"; }
+
+extern "C" const char *amt_status_string(int s)
+{
+    switch (s) {
+    case AMT_OK: return "ok";
+    case AMT_ERR_HIP: return "HIP runtime error";
+    case AMT_ERR_PRECONDITION: return "bounds violate the preconditions of advance_mu_t";
+    case AMT_ERR_INVALID_ARG: return "invalid argument";
+    case AMT_ERR_NO_DEVICE: return "no HIP device";
+    case AMT_ERR_ALLOC: return "allocation failed";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *amt_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int amt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int amt_compute_window(int periodic_x, int specified, int nested,
+                                  int ids, int ide, int jds, int jde,
+                                  int its, int ite, int jts, int jte, int kts, int kte,
+                                  int *i_start, int *i_end, int *j_start, int *j_end,
+                                  int *k_start, int *k_end)
+{
+    const AmtWindow w = amt_window(periodic_x, specified, nested, ids, ide, jds, jde,
+                                   its, ite, jts, jte, kts, kte);
+    if (i_start) *i_start = w.i_start;
+    if (i_end) *i_end = w.i_end;
+    if (j_start) *j_start = w.j_start;
+    if (j_end) *j_end = w.j_end;
+    if (k_start) *k_start = w.k_start;
+    if (k_end) *k_end = w.k_end;
+    return AMT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// argument bundle shared by the entry points
+// ---------------------------------------------------------------------------
+template <typename T>
+struct AmtArgs {
+    T *ww; const T *ww_1, *u, *u_1, *v, *v_1;
+    T *mu; const T *mut; T *muave, *muts; const T *muu, *muv;
+    T *mudf, *t; const T *t_1; T *t_ave; const T *ft, *mu_tend;
+    T rdx, rdy, dts, epssm;
+    const T *dnw, *fnm, *fnp, *rdnw, *msfuy, *msfvx_inv, *msftx, *msfty;
+    int periodic_x, specified, nested;
+    int ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte;
+};
+
+// Checks the preconditions and rebases the Fortran bounds to memory-relative
+// zero-based ones (cf. advance_mu_t_no_async.cu:57-85).  *empty is set when the
+// compute window holds no column (then nothing may be dereferenced).
+template <typename T>
+static int amt_build_params(const AmtArgs<T> &a, AmtParams<T> &p, AmtWindow &w, bool *empty)
+{
+    w = amt_window(a.periodic_x, a.specified, a.nested, a.ids, a.ide, a.jds, a.jde,
+                   a.its, a.ite, a.jts, a.jte, a.kts, a.kte);
+    *empty = (w.i_end < w.i_start) || (w.j_end < w.j_start);
+    if (a.ime < a.ims || a.jme < a.jms || a.kme < a.kms)
+        return amt_fail(AMT_ERR_PRECONDITION, "empty memory extents");
+    if (a.kts != 1 || a.kte != a.kde)
+        return amt_fail(AMT_ERR_PRECONDITION,
+                        "need kts == 1 and kte == kde (got kts=%d kte=%d kde=%d): the Fortran "
+                        "uses literal levels 1,2 and wdtn(kde) (module_small_step_em.f90:159,168,221)",
+                        a.kts, a.kte, a.kde);
+    if (a.kms > 1 || a.kme < a.kte)
+        return amt_fail(AMT_ERR_PRECONDITION, "levels 1..kte=%d not inside memory kms:kme=%d:%d",
+                        a.kte, a.kms, a.kme);
+    if (*empty) return AMT_OK;
+    if (w.i_start - 1 < a.ims || w.i_end + 1 > a.ime)
+        return amt_fail(AMT_ERR_PRECONDITION,
+                        "i window %d:%d plus halo not inside memory ims:ime=%d:%d",
+                        w.i_start, w.i_end, a.ims, a.ime);
+    if (w.j_start - 1 < a.jms || w.j_end + 1 > a.jme)
+        return amt_fail(AMT_ERR_PRECONDITION,
+                        "j window %d:%d plus halo not inside memory jms:jme=%d:%d",
+                        w.j_start, w.j_end, a.jms, a.jme);
+    const void *ptrs[] = {a.ww, a.ww_1, a.u, a.u_1, a.v, a.v_1, a.mu, a.mut, a.muave, a.muts,
+                          a.muu, a.muv, a.mudf, a.t, a.t_1, a.t_ave, a.ft, a.mu_tend, a.dnw,
+                          a.fnm, a.fnp, a.rdnw, a.msfuy, a.msfvx_inv, a.msftx, a.msfty};
+    for (const void *q : ptrs)
+        if (!q) return amt_fail(AMT_ERR_INVALID_ARG, "null array pointer");
+
+    p.ww = a.ww; p.mu = a.mu; p.muave = a.muave; p.muts = a.muts; p.mudf = a.mudf;
+    p.t = a.t; p.t_ave = a.t_ave;
+    p.ww_1 = a.ww_1; p.u = a.u; p.u_1 = a.u_1; p.v = a.v; p.v_1 = a.v_1; p.mut = a.mut;
+    p.muu = a.muu; p.muv = a.muv; p.t_1 = a.t_1; p.ft = a.ft; p.mu_tend = a.mu_tend;
+    p.dnw = a.dnw; p.fnm = a.fnm; p.fnp = a.fnp; p.rdnw = a.rdnw; p.msfuy = a.msfuy;
+    p.msfvx_inv = a.msfvx_inv; p.msftx = a.msftx; p.msfty = a.msfty;
+    p.rdx = a.rdx; p.rdy = a.rdy; p.dts = a.dts; p.epssm = a.epssm;
+    p.idim = a.ime - a.ims + 1;
+    p.kdim = a.kme - a.kms + 1;
+    p.jstride = (long)p.idim * p.kdim;
+    p.i0 = w.i_start - a.ims; p.i1 = w.i_end - a.ims;
+    p.j0 = w.j_start - a.jms; p.j1 = w.j_end - a.jms;
+    p.k1 = 1 - a.kms;
+    p.nk = w.k_end;            // levels 1..k_end (k_end may be 0)
+    return AMT_OK;
+}
+
+template <typename T>
+static int amt_launch(hipStream_t stream, int variant, const AmtParams<T> &p)
+{
+    if (variant == AMT_VARIANT_AUTO)
+        variant = amt_march_supported(p) ? AMT_VARIANT_MARCH : AMT_VARIANT_COLUMN;
+    hipError_t e;
+    if (variant == AMT_VARIANT_COLUMN) {
+        e = amt_launch_column<T>(stream, p);
+    } else if (variant == AMT_VARIANT_MARCH) {
+        if (!amt_march_supported(p))
+            return amt_fail(AMT_ERR_INVALID_ARG, "AMT_VARIANT_MARCH does not support nk=%d", p.nk);
+        e = amt_launch_march<T>(stream, p);
+    } else {
+        return amt_fail(AMT_ERR_INVALID_ARG, "unknown variant %d", variant);
+    }
+    if (e != hipSuccess)
+        return amt_fail(e == hipErrorNoDevice ? AMT_ERR_NO_DEVICE : AMT_ERR_HIP,
+                        "kernel launch failed: %s", hipGetErrorString(e));
+    return AMT_OK;
+}
+
+template <typename T>
+static int amt_device_call(void *hip_stream, int variant, const AmtArgs<T> &a)
+{
+    AmtParams<T> p;
+    AmtWindow w;
+    bool empty = false;
+    int rc = amt_build_params(a, p, w, &empty);
+    if (rc != AMT_OK || empty) return rc;
+    return amt_launch<T>(static_cast<hipStream_t>(hip_stream), variant, p);
+}
+
+// ---------------------------------------------------------------------------
+// (1) one-shot host drop-in
+// ---------------------------------------------------------------------------
+namespace {
+struct DeviceArena {
+    char *base = nullptr;
+    size_t size = 0, used = 0;
+    ~DeviceArena() { if (base) (void)hipFree(base); }
+    void *take(size_t bytes)
+    {
+        const size_t off = (used + 255) & ~(size_t)255;
+        used = off + bytes;
+        return base + off;
+    }
+};
+struct StreamGuard {
+    hipStream_t s = nullptr;
+    ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
+};
+}  // namespace
+
+template <typename T>
+static int amt_host_call(const AmtArgs<T> &h)
+{
+    AmtParams<T> p;
+    AmtWindow w;
+    bool empty = false;
+    int rc = amt_build_params(h, p, w, &empty);
+    if (rc != AMT_OK || empty) return rc;
+    int ndev = 0;
+    AMT_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return amt_fail(AMT_ERR_NO_DEVICE, "no HIP device visible");
+
+    // Device patch = the j rows the window touches plus one halo row each side
+    // (the stencil reads j-1 and j+1 of pure inputs only); all i, all k.
+    const int ja = w.j_start - 1, jb = w.j_end + 1;
+    const long idim = p.idim, kdim = p.kdim;
+    const long nrow = jb - ja + 1;
+    const size_t n3 = (size_t)idim * kdim * nrow, n2 = (size_t)idim * nrow, n1 = (size_t)kdim;
+    const size_t off3 = (size_t)(ja - h.jms) * idim * kdim, off2 = (size_t)(ja - h.jms) * idim;
+
+    DeviceArena arena;
+    arena.size = (10 * (n3 * sizeof(T) + 256)) + (12 * (n2 * sizeof(T) + 256)) + 4 * (n1 * sizeof(T) + 256);
+    if (hipMalloc((void **)&arena.base, arena.size) != hipSuccess) {
+        (void)hipGetLastError();
+        arena.base = nullptr;
+        return amt_fail(AMT_ERR_ALLOC, "hipMalloc of %zu bytes failed", arena.size);
+    }
+    StreamGuard sg;
+    AMT_HIP(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+
+    AmtArgs<T> d = h;
+    d.jms = ja; d.jme = jb;
+    // every array, OUT ones included (contents outside the window must survive,
+    // cf. advance_mu_t_no_async.cu:259,270-272)
+    struct Item { const T *host; const T **dev_c; T **dev_m; int rank; };
+    T *dww, *dmu, *dmuave, *dmuts, *dmudf, *dt, *dtave;
+    Item items[] = {
+        {h.ww, nullptr, &dww, 3}, {h.ww_1, &d.ww_1, nullptr, 3}, {h.u, &d.u, nullptr, 3},
+        {h.u_1, &d.u_1, nullptr, 3}, {h.v, &d.v, nullptr, 3}, {h.v_1, &d.v_1, nullptr, 3},
+        {h.mu, nullptr, &dmu, 2}, {h.mut, &d.mut, nullptr, 2}, {h.muave, nullptr, &dmuave, 2},
+        {h.muts, nullptr, &dmuts, 2}, {h.muu, &d.muu, nullptr, 2}, {h.muv, &d.muv, nullptr, 2},
+        {h.mudf, nullptr, &dmudf, 2}, {h.t, nullptr, &dt, 3}, {h.t_1, &d.t_1, nullptr, 3},
+        {h.t_ave, nullptr, &dtave, 3}, {h.ft, &d.ft, nullptr, 3}, {h.mu_tend, &d.mu_tend, nullptr, 2},
+        {h.dnw, &d.dnw, nullptr, 1}, {h.fnm, &d.fnm, nullptr, 1}, {h.fnp, &d.fnp, nullptr, 1},
+        {h.rdnw, &d.rdnw, nullptr, 1}, {h.msfuy, &d.msfuy, nullptr, 2},
+        {h.msfvx_inv, &d.msfvx_inv, nullptr, 2}, {h.msftx, &d.msftx, nullptr, 2},
+        {h.msfty, &d.msfty, nullptr, 2},
+    };
+    for (Item &it : items) {
+        const size_t n = it.rank == 3 ? n3 : it.rank == 2 ? n2 : n1;
+        const size_t off = it.rank == 3 ? off3 : it.rank == 2 ? off2 : 0;
+        T *dev = static_cast<T *>(arena.take(n * sizeof(T)));
+        AMT_HIP(hipMemcpyAsync(dev, it.host + off, n * sizeof(T), hipMemcpyHostToDevice, sg.s));
+        if (it.dev_c) *it.dev_c = dev; else *it.dev_m = dev;
+    }
+    d.ww = dww; d.mu = dmu; d.muave = dmuave; d.muts = dmuts; d.mudf = dmudf; d.t = dt; d.t_ave = dtave;
+
+    rc = amt_device_call<T>(sg.s, AMT_VARIANT_AUTO, d);
+    if (rc != AMT_OK) { (void)hipStreamSynchronize(sg.s); return rc; }
+
+    // outputs: rows j_start..j_end only (row 1 .. nrow-2 of the device patch)
+    const size_t o3 = (size_t)idim * kdim, o2 = (size_t)idim;
+    const size_t m3 = (size_t)idim * kdim * (nrow - 2), m2 = (size_t)idim * (nrow - 2);
+    struct Out { T *host; T *dev; int rank; };
+    Out outs[] = {{h.ww, dww, 3}, {h.t, dt, 3}, {h.t_ave, dtave, 3}, {h.mu, dmu, 2},
+                  {h.muave, dmuave, 2}, {h.muts, dmuts, 2}, {h.mudf, dmudf, 2}};
+    for (Out &o : outs) {
+        const size_t skip = o.rank == 3 ? o3 : o2, n = o.rank == 3 ? m3 : m2;
+        const size_t off = (o.rank == 3 ? off3 : off2) + skip;
+        AMT_HIP(hipMemcpyAsync(o.host + off, o.dev + skip, n * sizeof(T), hipMemcpyDeviceToHost, sg.s));
+    }
+    AMT_HIP(hipStreamSynchronize(sg.s));
+    return AMT_OK;
+}
+
+#define AMT_PACK_ARGS(T)                                                                        \
+    AmtArgs<T> a;                                                                               \
+    a.ww = ww; a.ww_1 = ww_1; a.u = u; a.u_1 = u_1; a.v = v; a.v_1 = v_1; a.mu = mu;            \
+    a.mut = mut; a.muave = muave; a.muts = muts; a.muu = muu; a.muv = muv; a.mudf = mudf;       \
+    a.t = t; a.t_1 = t_1; a.t_ave = t_ave; a.ft = ft; a.mu_tend = mu_tend;                      \
+    a.rdx = rdx; a.rdy = rdy; a.dts = dts; a.epssm = epssm;                                     \
+    a.dnw = dnw; a.fnm = fnm; a.fnp = fnp; a.rdnw = rdnw; a.msfuy = msfuy;                      \
+    a.msfvx_inv = msfvx_inv; a.msftx = msftx; a.msfty = msfty;                                  \
+    a.periodic_x = periodic_x; a.specified = specified; a.nested = nested;                      \
+    a.ids = ids; a.ide = ide; a.jds = jds; a.jde = jde; a.kde = kde;                            \
+    a.ims = ims; a.ime = ime; a.jms = jms; a.jme = jme; a.kms = kms; a.kme = kme;               \
+    a.its = its; a.ite = ite; a.jts = jts; a.jte = jte; a.kts = kts; a.kte = kte;
+
+#define AMT_SIG(T)                                                                              \
+    T *ww, const T *ww_1, const T *u, const T *u_1, const T *v, const T *v_1,                   \
+    T *mu, const T *mut, T *muave, T *muts, const T *muu, const T *muv,                         \
+    T *mudf, T *t, const T *t_1, T *t_ave, const T *ft, const T *mu_tend,                       \
+    T rdx, T rdy, T dts, T epssm,                                                               \
+    const T *dnw, const T *fnm, const T *fnp, const T *rdnw,                                    \
+    const T *msfuy, const T *msfvx_inv, const T *msftx, const T *msfty,                         \
+    int periodic_x, int specified, int nested,                                                  \
+    int ids, int ide, int jds, int jde, int kde,                                                \
+    int ims, int ime, int jms, int jme, int kms, int kme,                                       \
+    int its, int ite, int jts, int jte, int kts, int kte
+
+extern "C" int amt_advance_mu_t_f32(AMT_SIG(float))
+{
+    AMT_PACK_ARGS(float)
+    return amt_host_call<float>(a);
+}
+extern "C" int amt_advance_mu_t_f64(AMT_SIG(double))
+{
+    AMT_PACK_ARGS(double)
+    return amt_host_call<double>(a);
+}
+extern "C" int amt_advance_mu_t_device_f32(void *hip_stream, int variant, AMT_SIG(float))
+{
+    AMT_PACK_ARGS(float)
+    return amt_device_call<float>(hip_stream, variant, a);
+}
+extern "C" int amt_advance_mu_t_device_f64(void *hip_stream, int variant, AMT_SIG(double))
+{
+    AMT_PACK_ARGS(double)
+    return amt_device_call<double>(hip_stream, variant, a);
+}
+
+// ---------------------------------------------------------------------------
+// (4) synthetic inputs
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void amt_synth_fill_kernel(T *dst, int field, uint64_t seed,
+                                      long idim, long kdim, long jdim,
+                                      long gi0, long gk0, long gj0,
+                                      long gidim, long gkdim, long gjdim)
+{
+    const long n = idim * kdim * jdim;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const long li = e % idim;
+        const long lk = (e / idim) % kdim;
+        const long lj = e / (idim * kdim);
+        dst[e] = (T)amt_synth_value(field, seed, gi0 + li, gk0 + lk, gj0 + lj, gidim, gkdim, gjdim);
+    }
+}
+
+static int amt_synth_shape(int field, long &idim, long &kdim, long &jdim, long &gi0, long &gk0, long &gj0)
+{
+    if (field < 0 || field >= AMT_F_COUNT) return amt_fail(AMT_ERR_INVALID_ARG, "bad field id %d", field);
+    const int rank = amt_field_rank(field);
+    if (rank == 2) { kdim = 1; gk0 = 0; }
+    if (rank == 1) { idim = 1; jdim = 1; gi0 = 0; gj0 = 0; }
+    if (idim < 0 || kdim < 0 || jdim < 0) return amt_fail(AMT_ERR_INVALID_ARG, "negative extent");
+    return AMT_OK;
+}
+
+extern "C" int amt_synth_fill_host(int field, int dtype_bytes, void *dst, uint64_t seed,
+                                   long idim, long kdim, long jdim,
+                                   long gi0, long gk0, long gj0,
+                                   long gidim, long gkdim, long gjdim)
+{
+    int rc = amt_synth_shape(field, idim, kdim, jdim, gi0, gk0, gj0);
+    if (rc) return rc;
+    if (!dst) return amt_fail(AMT_ERR_INVALID_ARG, "null destination");
+    if (dtype_bytes != 4 && dtype_bytes != 8) return amt_fail(AMT_ERR_INVALID_ARG, "dtype_bytes must be 4 or 8");
+    long e = 0;
+    for (long lj = 0; lj < jdim; ++lj)
+        for (long lk = 0; lk < kdim; ++lk)
+            for (long li = 0; li < idim; ++li, ++e) {
+                const double x = amt_synth_value(field, seed, gi0 + li, gk0 + lk, gj0 + lj, gidim, gkdim, gjdim);
+                if (dtype_bytes == 8) static_cast<double *>(dst)[e] = x;
+                else static_cast<float *>(dst)[e] = (float)x;
+            }
+    return AMT_OK;
+}
+
+extern "C" int amt_synth_fill_device(void *hip_stream, int field, int dtype_bytes, void *dst,
+                                     uint64_t seed, long idim, long kdim, long jdim,
+                                     long gi0, long gk0, long gj0,
+                                     long gidim, long gkdim, long gjdim)
+{
+    int rc = amt_synth_shape(field, idim, kdim, jdim, gi0, gk0, gj0);
+    if (rc) return rc;
+    if (!dst) return amt_fail(AMT_ERR_INVALID_ARG, "null destination");
+    if (dtype_bytes != 4 && dtype_bytes != 8) return amt_fail(AMT_ERR_INVALID_ARG, "dtype_bytes must be 4 or 8");
+    const long n = idim * kdim * jdim;
+    if (n == 0) return AMT_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (dtype_bytes == 8)
+        hipLaunchKernelGGL(amt_synth_fill_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<double *>(dst), field, seed, idim, kdim, jdim, gi0, gk0, gj0,
+                           gidim, gkdim, gjdim);
+    else
+        hipLaunchKernelGGL(amt_synth_fill_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<float *>(dst), field, seed, idim, kdim, jdim, gi0, gk0, gj0,
+                           gidim, gkdim, gjdim);
+    AMT_HIP(hipGetLastError());
+    return AMT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// (3) resident domain handle
+// ---------------------------------------------------------------------------
+struct amt_domain {
+    int dtype_bytes = 8;
+    int periodic_x = 0, specified = 0, nested = 0;
+    int ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte;
+    double rdx = AMT_SYNTH_RDX, rdy = AMT_SYNTH_RDY, dts = AMT_SYNTH_DTS, epssm = AMT_SYNTH_EPSSM;
+    int variant = AMT_VARIANT_AUTO;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *field[AMT_F_COUNT] = {};
+    size_t count(int f) const
+    {
+        const size_t idim = ime - ims + 1, kdim = kme - kms + 1, jdim = jme - jms + 1;
+        const int r = amt_field_rank(f);
+        return r == 3 ? idim * kdim * jdim : r == 2 ? idim * jdim : kdim;
+    }
+};
+
+extern "C" int amt_domain_destroy(amt_domain *d)
+{
+    if (!d) return AMT_OK;
+    for (void *&q : d->field)
+        if (q) { (void)hipFree(q); q = nullptr; }
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_create(amt_domain **out, int dtype_bytes,
+                                 int periodic_x, int specified, int nested,
+                                 int ids, int ide, int jds, int jde, int kde,
+                                 int ims, int ime, int jms, int jme, int kms, int kme,
+                                 int its, int ite, int jts, int jte, int kts, int kte)
+{
+    if (!out) return amt_fail(AMT_ERR_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    if (dtype_bytes != 4 && dtype_bytes != 8) return amt_fail(AMT_ERR_INVALID_ARG, "dtype_bytes must be 4 or 8");
+    if (ime < ims || jme < jms || kme < kms) return amt_fail(AMT_ERR_PRECONDITION, "empty memory extents");
+    int ndev = 0;
+    AMT_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return amt_fail(AMT_ERR_NO_DEVICE, "no HIP device visible");
+    amt_domain *d = new (std::nothrow) amt_domain;
+    if (!d) return amt_fail(AMT_ERR_ALLOC, "host allocation failed");
+    d->dtype_bytes = dtype_bytes;
+    d->periodic_x = periodic_x; d->specified = specified; d->nested = nested;
+    d->ids = ids; d->ide = ide; d->jds = jds; d->jde = jde; d->kde = kde;
+    d->ims = ims; d->ime = ime; d->jms = jms; d->jme = jme; d->kms = kms; d->kme = kme;
+    d->its = its; d->ite = ite; d->jts = jts; d->jte = jte; d->kts = kts; d->kte = kte;
+    hipError_t e = hipGetDevice(&d->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&d->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&d->ev1);
+    for (int f = 0; f < AMT_F_COUNT && e == hipSuccess; ++f)
+        e = hipMalloc(&d->field[f], d->count(f) * (size_t)dtype_bytes);
+    if (e != hipSuccess) {
+        amt_domain_destroy(d);
+        return amt_fail(e == hipErrorOutOfMemory ? AMT_ERR_ALLOC : AMT_ERR_HIP,
+                        "amt_domain_create: %s", hipGetErrorString(e));
+    }
+    *out = d;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_set_scalars(amt_domain *d, double rdx, double rdy, double dts, double epssm)
+{
+    if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    d->rdx = rdx; d->rdy = rdy; d->dts = dts; d->epssm = epssm;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_set_variant(amt_domain *d, int variant)
+{
+    if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    if (variant < AMT_VARIANT_AUTO || variant > AMT_VARIANT_MARCH)
+        return amt_fail(AMT_ERR_INVALID_ARG, "unknown variant %d", variant);
+    d->variant = variant;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_upload(amt_domain *d, int field, const void *host)
+{
+    if (!d || !host || field < 0 || field >= AMT_F_COUNT) return amt_fail(AMT_ERR_INVALID_ARG, "bad upload argument");
+    AMT_HIP(hipMemcpyAsync(d->field[field], host, d->count(field) * d->dtype_bytes, hipMemcpyHostToDevice, d->stream));
+    AMT_HIP(hipStreamSynchronize(d->stream));
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_download(amt_domain *d, int field, void *host)
+{
+    if (!d || !host || field < 0 || field >= AMT_F_COUNT) return amt_fail(AMT_ERR_INVALID_ARG, "bad download argument");
+    AMT_HIP(hipMemcpyAsync(host, d->field[field], d->count(field) * d->dtype_bytes, hipMemcpyDeviceToHost, d->stream));
+    AMT_HIP(hipStreamSynchronize(d->stream));
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,
+                                         long gi0, long gk0, long gj0,
+                                         long gidim, long gkdim, long gjdim)
+{
+    if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    const long idim = d->ime - d->ims + 1, kdim = d->kme - d->kms + 1, jdim = d->jme - d->jms + 1;
+    for (int f = 0; f < AMT_F_COUNT; ++f) {
+        int rc = amt_synth_fill_device(d->stream, f, d->dtype_bytes, d->field[f], seed,
+                                       idim, kdim, jdim, gi0, gk0, gj0, gidim, gkdim, gjdim);
+        if (rc) return rc;
+    }
+    return AMT_OK;
+}
+
+template <typename T>
+static int amt_domain_step_t(amt_domain *d, int n_sweeps)
+{
+    AmtArgs<T> a;
+    T **f = reinterpret_cast<T **>(d->field);
+    a.ww = f[AMT_F_WW]; a.ww_1 = f[AMT_F_WW_1]; a.u = f[AMT_F_U]; a.u_1 = f[AMT_F_U_1];
+    a.v = f[AMT_F_V]; a.v_1 = f[AMT_F_V_1]; a.mu = f[AMT_F_MU]; a.mut = f[AMT_F_MUT];
+    a.muave = f[AMT_F_MUAVE]; a.muts = f[AMT_F_MUTS]; a.muu = f[AMT_F_MUU]; a.muv = f[AMT_F_MUV];
+    a.mudf = f[AMT_F_MUDF]; a.t = f[AMT_F_T]; a.t_1 = f[AMT_F_T_1]; a.t_ave = f[AMT_F_T_AVE];
+    a.ft = f[AMT_F_FT]; a.mu_tend = f[AMT_F_MU_TEND];
+    a.rdx = (T)d->rdx; a.rdy = (T)d->rdy; a.dts = (T)d->dts; a.epssm = (T)d->epssm;
+    a.dnw = f[AMT_F_DNW]; a.fnm = f[AMT_F_FNM]; a.fnp = f[AMT_F_FNP]; a.rdnw = f[AMT_F_RDNW];
+    a.msfuy = f[AMT_F_MSFUY]; a.msfvx_inv = f[AMT_F_MSFVX_INV]; a.msftx = f[AMT_F_MSFTX];
+    a.msfty = f[AMT_F_MSFTY];
+    a.periodic_x = d->periodic_x; a.specified = d->specified; a.nested = d->nested;
+    a.ids = d->ids; a.ide = d->ide; a.jds = d->jds; a.jde = d->jde; a.kde = d->kde;
+    a.ims = d->ims; a.ime = d->ime; a.jms = d->jms; a.jme = d->jme; a.kms = d->kms; a.kme = d->kme;
+    a.its = d->its; a.ite = d->ite; a.jts = d->jts; a.jte = d->jte; a.kts = d->kts; a.kte = d->kte;
+    for (int s = 0; s < n_sweeps; ++s) {
+        int rc = amt_device_call<T>(d->stream, d->variant, a);
+        if (rc) return rc;
+    }
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_step(amt_domain *d, int n_sweeps)
+{
+    if (!d || n_sweeps < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad step argument");
+    return d->dtype_bytes == 8 ? amt_domain_step_t<double>(d, n_sweeps) : amt_domain_step_t<float>(d, n_sweeps);
+}
+
+extern "C" int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_total)
+{
+    if (!d || n_sweeps < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad step argument");
+    AMT_HIP(hipEventRecord(d->ev0, d->stream));
+    int rc = amt_domain_step(d, n_sweeps);
+    if (rc) return rc;
+    AMT_HIP(hipEventRecord(d->ev1, d->stream));
+    AMT_HIP(hipEventSynchronize(d->ev1));
+    float ms = 0.f;
+    AMT_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+    if (ms_total) *ms_total = ms;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_sync(amt_domain *d)
+{
+    if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    AMT_HIP(hipStreamSynchronize(d->stream));
+    return AMT_OK;
+}
+
+extern "C" void *amt_domain_field_ptr(amt_domain *d, int field)
+{
+    if (!d || field < 0 || field >= AMT_F_COUNT) return nullptr;
+    return d->field[field];
+}
+
+extern "C" void *amt_domain_stream(amt_domain *d) { return d ? (void *)d->stream : nullptr; }

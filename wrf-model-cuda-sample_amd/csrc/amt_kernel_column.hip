@@ -1,0 +1,132 @@
+// amt_kernel_column.hip -- AMT_VARIANT_COLUMN: one lane per (i,j) column.
+//
+// First, simplest gfx950 kernel of the path (kept as the cross-check for the
+// faster AMT_VARIANT_MARCH kernel).  Lanes of a wave64 are 64 consecutive i of one
+// j-row, so every 3-D access of the wave is one contiguous 64*sizeof(T) segment
+// (i-contiguous coalesced loads); each lane walks its own k-column twice:
+//   pass 1  dvdxi(k) -> LDS column [k][lane], dmdt = sum_k dnw(k)*dvdxi(k)
+//           (module_small_step_em.f90:140-149), then the 2-D mass update (:151-157)
+//   pass 2  ww recurrence (:159-172), theta pre-update (:208-215), vertical flux
+//           (:219-229) and flux-form theta update (:234-248), fused per level.
+// The three Fortran phases fuse into one launch because a column never reads
+// another column's outputs.  Each expression keeps the
+// Fortran association and the file is compiled with -ffp-contract=off, so the
+// results are bit-identical to the Fortran (no FMA, IEEE divide, the
+// sequential k order of the dmdt sum and of the ww recurrence).
+//
+// No __syncthreads(): a lane only ever reads the LDS words it wrote itself.
+#include <hip/hip_runtime.h>
+#include "amt_params.h"
+
+template <typename T>
+__global__ __launch_bounds__(64) void amt_column_kernel(const AmtParams<T> p, const int ntile_i)
+{
+    extern __shared__ __align__(16) unsigned char amt_smem[];
+    T *dv = reinterpret_cast<T *>(amt_smem);          // [nk][64]
+
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x % ntile_i;
+    const int jrow = blockIdx.x / ntile_i;
+    const int ii   = tile * 64 + lane;                // zero-based memory i
+    const int jj   = p.j0 + jrow;                     // zero-based memory j
+    if (ii < p.i0 || ii > p.i1) return;
+
+    const long idim = p.idim;
+    const long js   = p.jstride;
+    const long c2   = (long)jj * idim + ii;           // (i,j) of 2-D arrays
+    const long c3   = (long)jj * js + (long)p.k1 * idim + ii;   // (i,k=1,j)
+
+    const T msftx = p.msftx[c2], msfty = p.msfty[c2];
+    const T muu_i = p.muu[c2], muu_ip = p.muu[c2 + 1];
+    const T msfuy_i = p.msfuy[c2], msfuy_ip = p.msfuy[c2 + 1];
+    const T muv_j = p.muv[c2], muv_jp = p.muv[c2 + idim];
+    const T mvx_j = p.msfvx_inv[c2], mvx_jp = p.msfvx_inv[c2 + idim];
+    const T mu_tend = p.mu_tend[c2];
+    const T rdx = p.rdx, rdy = p.rdy, dts = p.dts;
+    const int nk = p.nk;
+    const T *dnw = p.dnw + p.k1, *fnm = p.fnm + p.k1, *fnp = p.fnp + p.k1, *rdnw = p.rdnw + p.k1;
+    // dnw[k-1] etc. below: index 0 is Fortran level 1
+
+    // ---- pass 1: divergence and column integral (:140-149) ----
+    T dmdt = T(0);
+    for (int k = 0; k < nk; ++k) {
+        const long c = c3 + (long)k * idim;
+        const T d = msftx * msfty * (
+              rdy * ( (p.v[c + js] + muv_jp * p.v_1[c + js] * mvx_jp)
+                    - (p.v[c     ] + muv_j  * p.v_1[c     ] * mvx_j ) )
+            + rdx * ( (p.u[c + 1] + muu_ip * p.u_1[c + 1] / msfuy_ip)
+                    - (p.u[c    ] + muu_i  * p.u_1[c    ] / msfuy_i ) ));
+        dv[k * 64 + lane] = d;
+        dmdt = dmdt + dnw[k] * d;
+    }
+
+    // ---- 2-D mass update (:151-157) ----
+    {
+        const T mu_old = p.mu[c2];
+        const T mu_new = mu_old + dts * (dmdt + mu_tend);
+        p.mu[c2]    = mu_new;
+        p.mudf[c2]  = (dmdt + mu_tend);
+        p.muts[c2]  = p.mut[c2] + mu_new;
+        p.muave[c2] = T(.5) * ((T(1.) + p.epssm) * mu_new + (T(1.) - p.epssm) * mu_old);
+    }
+    if (nk < 1) return;
+
+    // ---- pass 2: ww recurrence + theta, fused per level ----
+    // ww_un : ww(k) of the recurrence (:161), before ww_1 is subtracted (:170)
+    // wd_k  : wdtn(k) (:220,:227)
+    T ww_un = p.ww[c3];
+    T wout  = ww_un - p.ww_1[c3];
+    T wd_k  = T(0);                                   // wdtn(i,1) = 0
+    T t1_k  = p.t_1[c3];                              // t_1(i,k,j)
+    for (int k = 0; k < nk; ++k) {                    // Fortran level k+1
+        const long c = c3 + (long)k * idim;
+        T wout_n = T(0), wd_n = T(0), t1_n = T(0);
+        if (k + 1 < nk) {
+            ww_un  = ww_un - dnw[k] * (dmdt + dv[k * 64 + lane] + mu_tend) / msfty;   // :161
+            wout_n = ww_un - p.ww_1[c + idim];                                         // :170
+            t1_n   = p.t_1[c + idim];
+            wd_n   = wout_n * (fnm[k + 1] * t1_n + fnp[k + 1] * t1_k);                 // :227
+        }                                             // else wdtn(i,kde) = 0 (:221)
+        p.ww[c] = wout;
+
+        const T t_old = p.t[c];
+        p.t_ave[c] = t_old;                                                            // :211
+        const T t_b = t_old + msfty * dts * p.ft[c];                                   // :212
+        p.t[c] = t_b - dts * msfty * (                                                 // :237-246
+                    msftx * (
+                        T(.5) * rdy *
+                          ( p.v[c + js] * (p.t_1[c + js] + t1_k)
+                          - p.v[c     ] * (t1_k + p.t_1[c - js]) )
+                      + T(.5) * rdx *
+                          ( p.u[c + 1] * (p.t_1[c + 1] + t1_k)
+                          - p.u[c    ] * (t1_k + p.t_1[c - 1]) ) )
+                  + rdnw[k] * (wd_n - wd_k) );
+        wout = wout_n; wd_k = wd_n; t1_k = t1_n;
+    }
+}
+
+template <typename T>
+hipError_t amt_launch_column(hipStream_t stream, const AmtParams<T> &p)
+{
+    const int ni = p.i1 - p.i0 + 1, nj = p.j1 - p.j0 + 1;
+    if (ni <= 0 || nj <= 0) return hipSuccess;
+    const int tile_lo = p.i0 / 64, tile_hi = p.i1 / 64;
+    const int ntile_i = tile_hi - tile_lo + 1;
+    AmtParams<T> q = p;
+    // shift the tile origin so that tile 0 is the first tile holding a window column
+    // (lanes stay aligned to multiples of 64 elements from the row start)
+    const long shift = (long)tile_lo * 64;
+    q.ww += shift; q.mu += shift; q.muave += shift; q.muts += shift; q.mudf += shift;
+    q.t += shift; q.t_ave += shift; q.ww_1 += shift; q.u += shift; q.u_1 += shift;
+    q.v += shift; q.v_1 += shift; q.mut += shift; q.muu += shift; q.muv += shift;
+    q.t_1 += shift; q.ft += shift; q.mu_tend += shift; q.msfuy += shift;
+    q.msfvx_inv += shift; q.msftx += shift; q.msfty += shift;
+    q.i0 -= (int)shift; q.i1 -= (int)shift;
+    const size_t lds = (size_t)(p.nk > 0 ? p.nk : 1) * 64 * sizeof(T);
+    const unsigned grid = (unsigned)((long)ntile_i * nj);
+    hipLaunchKernelGGL(amt_column_kernel<T>, dim3(grid), dim3(64), lds, stream, q, ntile_i);
+    return hipGetLastError();
+}
+
+template hipError_t amt_launch_column<float>(hipStream_t, const AmtParams<float> &);
+template hipError_t amt_launch_column<double>(hipStream_t, const AmtParams<double> &);

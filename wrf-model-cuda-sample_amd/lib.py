@@ -1,0 +1,90 @@
+"""ctypes binding of the C-ABI declared in include/amt_advance_mu_t.h.
+
+This is the "reference-side binding" a Python host would add (INTEGRATION.md shows the
+Fortran ISO_C_BINDING and C ones).  Loading fails loudly when the HIP library has not
+been built -- there is no fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+_LIB_NAME = "libamt_advance_mu_t.so"
+
+# status codes of include/amt_advance_mu_t.h
+OK, ERR_HIP, ERR_PRECONDITION, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_ALLOC = range(6)
+
+
+class AmtError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"amt status {status}: {message}")
+        self.status = status
+
+
+def library_path() -> Path:
+    return PKG_DIR / _LIB_NAME
+
+
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_long
+
+
+def _adv_sig(real, device: bool):
+    head = [_P, _I] if device else []
+    return head + [_P] * 18 + [real] * 4 + [_P] * 8 + [_I] * (3 + 17)
+
+
+# every symbol include/amt_advance_mu_t.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "amt_version": (ctypes.c_char_p, []),
+    "amt_status_string": (ctypes.c_char_p, [_I]),
+    "amt_last_error": (ctypes.c_char_p, []),
+    "amt_device_count": (_I, []),
+    "amt_advance_mu_t_f32": (_I, _adv_sig(ctypes.c_float, False)),
+    "amt_advance_mu_t_f64": (_I, _adv_sig(ctypes.c_double, False)),
+    "amt_advance_mu_t_device_f32": (_I, _adv_sig(ctypes.c_float, True)),
+    "amt_advance_mu_t_device_f64": (_I, _adv_sig(ctypes.c_double, True)),
+    "amt_compute_window": (_I, [_I] * 13 + [ctypes.POINTER(_I)] * 6),
+    "amt_domain_create": (_I, [ctypes.POINTER(_P), _I] + [_I] * 20),
+    "amt_domain_destroy": (_I, [_P]),
+    "amt_domain_set_scalars": (_I, [_P] + [ctypes.c_double] * 4),
+    "amt_domain_set_variant": (_I, [_P, _I]),
+    "amt_domain_upload": (_I, [_P, _I, _P]),
+    "amt_domain_download": (_I, [_P, _I, _P]),
+    "amt_domain_fill_synthetic": (_I, [_P, ctypes.c_uint64] + [_L] * 6),
+    "amt_domain_step": (_I, [_P, _I]),
+    "amt_domain_step_timed": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
+    "amt_domain_sync": (_I, [_P]),
+    "amt_domain_field_ptr": (_P, [_P, _I]),
+    "amt_domain_stream": (_P, [_P]),
+    "amt_synth_fill_host": (_I, [_I, _I, _P, ctypes.c_uint64] + [_L] * 9),
+    "amt_synth_fill_device": (_I, [_P, _I, _I, _P, ctypes.c_uint64] + [_L] * 9),
+}
+
+
+def load_library() -> ctypes.CDLL:
+    """Load the HIP library (once).  torch, when used in the same process, must be imported
+    first so that both share one HIP runtime (same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not path.exists():
+            raise AmtError(ERR_NO_DEVICE, f"{path} not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                          "(make -C wrf-model-cuda-sample_amd/csrc); there is no CPU fallback")
+        L = ctypes.CDLL(str(path))
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != OK:
+        L = load_library()
+        msg = L.amt_last_error().decode() or L.amt_status_string(status).decode()
+        raise AmtError(status, msg)

@@ -1,0 +1,130 @@
+"""j-slab decomposition of advance_mu_t with a one-row input-halo exchange.
+
+The reference splits the domain statically on j across its GPUs and refills three
+redundant halo rows per side from the host copy on every call, with no inter-GPU
+communication (advance_mu_t_no_async.cu:108-162).  Here one process owns one GPU and one
+contiguous j-slab (``synth.slab_bounds``), keeps it resident, and before each sweep trades
+exactly the rows the stencil reads across a slab edge:
+
+  * from the slab above (j+1):  row jhi+1 of  v, v_1, t_1 (3-D)  and  muv, msfvx_inv (2-D)
+    (module_small_step_em.f90:143, :241)
+  * from the slab below (j-1):  row jlo-1 of  t_1                                  (:242)
+
+All of them are pure inputs, so the exchange runs on a second stream while the interior
+rows jlo+1..jhi-1 are computed; only the two edge rows wait for it.  In (i,k,j) layout a
+j-row is one contiguous run of idim*kdim elements, so rows are sent in place (no packing).
+Transport: ``torch.distributed`` point-to-point -- backend "nccl" is RCCL send/recv over
+xGMI on ROCm; the same code runs over "gloo" on CPU tensors in the tests.  No collective
+is needed anywhere in this path.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+from .synth import Patch, HALO_FROM_ABOVE, HALO_FROM_BELOW
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+class SlabStepper:
+    """Runs advance_mu_t sweeps on one j-slab of a domain split over ``world`` ranks.
+
+    ``patch``   : this rank's Patch (bounds from ``synth.slab_bounds``; arrays are torch
+                  tensors -- CUDA for the product path, CPU in the gloo tests).
+    ``compute`` : callable(*the 48 advance_mu_t arguments, stream=...) that updates a tile in
+                  place.  The product passes ``api.advance_mu_t`` (HIP); there is no default
+                  CPU implementation.
+    """
+
+    def __init__(self, patch: Patch, rank: int, world: int, compute: Callable, *,
+                 group=None, overlap: bool = True, variant: int = 0):
+        self.patch, self.rank, self.world = patch, rank, world
+        self.compute, self.group, self.overlap, self.variant = compute, group, overlap, variant
+        self.below: Optional[int] = rank - 1 if rank > 0 else None
+        self.above: Optional[int] = rank + 1 if rank < world - 1 else None
+        any_arr = patch.arrays["t_1"]
+        self.on_gpu = bool(getattr(any_arr, "is_cuda", False))
+        self.main_stream = self.comm_stream = None
+        if self.on_gpu:
+            import torch
+            self.main_stream = torch.cuda.current_stream(any_arr.device)
+            self.comm_stream = torch.cuda.Stream(device=any_arr.device)
+        b = patch.bounds
+        if world > 1 and (b.jme - b.jms + 1) != (b.jte - b.jts + 1) + 2:
+            raise ValueError("a slab patch holds its rows plus exactly one halo row per side")
+
+    # -- halo exchange -----------------------------------------------------------------
+    def _p2p_ops(self):
+        dist = _dist()
+        a = self.patch.arrays
+        jdim = self.patch.bounds.jdim
+        first_owned, last_owned, halo_lo, halo_hi = 1, jdim - 2, 0, jdim - 1
+        ops = []
+        # order per peer pair is fixed (NCCL/RCCL matches send/recv by order, gloo by tag)
+        if self.below is not None:
+            for n, name in enumerate(HALO_FROM_ABOVE):     # my first row is their row jhi+1
+                ops.append(dist.P2POp(dist.isend, a[name][first_owned], self.below, self.group, tag=10 + n))
+            for n, name in enumerate(HALO_FROM_BELOW):
+                ops.append(dist.P2POp(dist.irecv, a[name][halo_lo], self.below, self.group, tag=20 + n))
+        if self.above is not None:
+            for n, name in enumerate(HALO_FROM_ABOVE):
+                ops.append(dist.P2POp(dist.irecv, a[name][halo_hi], self.above, self.group, tag=10 + n))
+            for n, name in enumerate(HALO_FROM_BELOW):     # my last row is their row jlo-1
+                ops.append(dist.P2POp(dist.isend, a[name][last_owned], self.above, self.group, tag=20 + n))
+        return ops
+
+    def exchange_halos(self):
+        """Post the sends/receives of one sweep and wait for them on the current stream
+        (device-side wait for RCCL; host wait for gloo)."""
+        ops = self._p2p_ops()
+        if not ops:
+            return
+        for req in _dist().batch_isend_irecv(ops):
+            req.wait()
+
+    def halo_bytes_per_sweep(self) -> int:
+        """Bytes this rank sends + receives per sweep."""
+        a = self.patch.arrays
+        n = 0
+        for peer, names in ((self.below, HALO_FROM_ABOVE + HALO_FROM_BELOW),
+                            (self.above, HALO_FROM_ABOVE + HALO_FROM_BELOW)):
+            if peer is not None:
+                n += sum(a[name][0].numel() * a[name].element_size() for name in names)
+        return n
+
+    # -- one sweep ---------------------------------------------------------------------
+    def _tile(self, jts: int, jte: int, stream):
+        if jte < jts:
+            return
+        args = self.patch.with_bounds(jts=jts, jte=jte).args()
+        if self.on_gpu:
+            self.compute(*args, stream=stream, variant=self.variant)
+        else:
+            self.compute(*args)
+
+    def step(self):
+        b = self.patch.bounds
+        jlo, jhi = b.jts, b.jte
+        if self.world == 1 or (self.below is None and self.above is None):
+            self._tile(jlo, jhi, self.main_stream)
+            return
+        # rows that read a neighbour's data: jlo (if there is a slab below), jhi (if above)
+        in_lo = jlo + (1 if self.below is not None else 0)
+        in_hi = jhi - (1 if self.above is not None else 0)
+        if self.on_gpu and self.overlap:
+            import torch
+            self.comm_stream.wait_stream(self.main_stream)      # inputs of this sub-step are final
+            with torch.cuda.stream(self.comm_stream):
+                self.exchange_halos()                           # RCCL send/recv on the comm stream
+            self._tile(in_lo, in_hi, self.main_stream)          # interior overlaps the exchange
+            self.main_stream.wait_stream(self.comm_stream)
+        else:
+            self.exchange_halos()
+            self._tile(in_lo, in_hi, self.main_stream)
+        if self.below is not None:
+            self._tile(jlo, min(jlo, jhi), self.main_stream)
+        if self.above is not None and (jhi > jlo or self.below is None):
+            self._tile(jhi, jhi, self.main_stream)
