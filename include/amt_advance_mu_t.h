@@ -206,6 +206,15 @@ int amt_synth_fill_device(void *hip_stream, int field, int dtype_bytes, void *ds
                           long gi0, long gk0, long gj0,
                           long gidim, long gkdim, long gjdim);
 
+/* ------------------------------------------------------------------------
+ * (5) Profiling aid: a plain streaming copy of nbytes (device to device) that moves
+ *     bytes_per_lane = 4, 8 or 16 bytes per lane per access -- a KNOWN byte count in
+ *     the kernels' own access width, used to calibrate rocprofv3's FETCH_SIZE /
+ *     WRITE_SIZE on gfx950 (profiles/README.md).
+ * ------------------------------------------------------------------------ */
+int amt_calib_stream_copy(void *hip_stream, void *dst_device, const void *src_device,
+                          size_t nbytes, int bytes_per_lane);
+
 #ifdef __cplusplus
 }
 #endif

@@ -579,3 +579,33 @@ extern "C" void *amt_domain_field_ptr(amt_domain *d, int field)
 }
 
 extern "C" void *amt_domain_stream(amt_domain *d) { return d ? (void *)d->stream : nullptr; }
+
+// ---------------------------------------------------------------------------
+// (5) profiling aid: streaming copy with a chosen access width
+// ---------------------------------------------------------------------------
+template <typename V>
+__global__ void amt_calib_copy_kernel(V *dst, const V *src, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) dst[e] = src[e];
+}
+
+extern "C" int amt_calib_stream_copy(void *hip_stream, void *dst, const void *src, size_t nbytes, int bytes_per_lane)
+{
+    if (!dst || !src) return amt_fail(AMT_ERR_INVALID_ARG, "null pointer");
+    if (bytes_per_lane != 4 && bytes_per_lane != 8 && bytes_per_lane != 16)
+        return amt_fail(AMT_ERR_INVALID_ARG, "bytes_per_lane must be 4, 8 or 16");
+    if (nbytes % bytes_per_lane) return amt_fail(AMT_ERR_INVALID_ARG, "nbytes not a multiple of the access width");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const size_t n = nbytes / bytes_per_lane;
+    if (n == 0) return AMT_OK;
+    const unsigned blocks = 256 * 8;
+    if (bytes_per_lane == 4)
+        hipLaunchKernelGGL(amt_calib_copy_kernel<float>, dim3(blocks), dim3(256), 0, s, (float *)dst, (const float *)src, n);
+    else if (bytes_per_lane == 8)
+        hipLaunchKernelGGL(amt_calib_copy_kernel<double>, dim3(blocks), dim3(256), 0, s, (double *)dst, (const double *)src, n);
+    else
+        hipLaunchKernelGGL(amt_calib_copy_kernel<double2>, dim3(blocks), dim3(256), 0, s, (double2 *)dst, (const double2 *)src, n);
+    AMT_HIP(hipGetLastError());
+    return AMT_OK;
+}

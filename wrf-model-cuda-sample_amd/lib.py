@@ -63,6 +63,7 @@ SYMBOLS = {
     "amt_domain_stream": (_P, [_P]),
     "amt_synth_fill_host": (_I, [_I, _I, _P, ctypes.c_uint64] + [_L] * 9),
     "amt_synth_fill_device": (_I, [_P, _I, _I, _P, ctypes.c_uint64] + [_L] * 9),
+    "amt_calib_stream_copy": (_I, [_P, _P, _P, ctypes.c_size_t, _I]),
 }
 
 
