@@ -1,9 +1,382 @@
-// amt_kernel_march.hip -- AMT_VARIANT_MARCH (placeholder until the kernel lands).
+// amt_kernel_march.hip -- AMT_VARIANT_MARCH: (i,k)-cell lanes marching in j.
+//
+// Why: the column kernel reads v, v_1 twice (rows j and j+1) and t_1 three times
+// (j-1, j, j+1) from beyond L2 -- rocprofv3 shows 1.97x the compulsory read bytes
+// (profiles/r01_column_pmc.json).  This kernel reads every input element once per sweep:
+//
+//  * A workgroup owns one 64-wide i-tile (memory aligned), ALL levels, and a block
+//    of consecutive j rows that it marches through.  Lane = i (so every 3-D access
+//    of a wave is one contiguous 64*sizeof(T) run: i-contiguous coalesced loads);
+//    wave w owns the KPT consecutive levels w*KPT+1 .. (w+1)*KPT.
+//  * The j-direction face fluxes  v(j)+muv(j)*v_1(j)*msfvx_inv(j)  and
+//    v(j)*(t_1(j)+t_1(j-1))  and the t_1 row itself are carried in registers from
+//    one row to the next (the face j+1 of row j IS the face j of row j+1: the same
+//    expression on the same operands, so carrying it is bit-exact).
+//  * The three k-dependencies go through LDS (k-column staging):
+//      A[k][lane] = dvdxi(i,k)   -> every wave sums the column in the Fortran's
+//                                   sequential k order (dmdt), bit-exact
+//      B[k][lane] = dnw(k)*(dmdt+dvdxi(k)+mu_tend)/msfty  (the ww increment; one divide
+//                                   per cell, computed once by the wave owning the level)
+//                                -> every wave runs the sequential prefix
+//                                   ww(k+1) = ww(k) - B[k] up to its own levels
+//    wdtn(k+1) across a wave boundary is recomputed from one extra ww_1/t_1 level.
+//    Two workgroup barriers per j row.
+//  * Expressions keep the Fortran association; built with -ffp-contract=off.
+//
+// Reference semantics: module_small_step_em.f90:112-172 (mu, ww), :208-215 and
+// :217-250 (theta); the fusion of the three Fortran phases is legal because a
+// column never reads another column's outputs.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "amt_params.h"
 
-template <typename T> bool amt_march_supported(const AmtParams<T> &) { return false; }
-template <typename T> hipError_t amt_launch_march(hipStream_t, const AmtParams<T> &) { return hipErrorNotSupported; }
+struct AmtMarchGrid {
+    int ntile_i;     // number of 64-wide i tiles that hold window columns
+    int tile_lo;     // first such tile
+    int jrows;       // rows per workgroup
+    int njblk;       // number of j blocks
+    int nwg;         // ntile_i * njblk
+};
+
+// Uniform-base addressing: every global access is  (wave-uniform pointer in SGPRs) +
+// (32-bit per-lane byte offset) [+ immediate], i.e. `global_load ... v_off, s[base:base+1]`.
+// 64-bit per-lane addresses would cost two VGPRs per distinct address and spill.
+template <typename T>
+__device__ __forceinline__ T amt_ld(const T *ubase, unsigned voff)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(ubase) + voff);
+}
+template <typename T>
+__device__ __forceinline__ void amt_st(T *ubase, unsigned voff, T x)
+{
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(ubase) + voff) = x;
+}
+
+// FULL: nk is a multiple of KPT (every wave owns exactly KPT levels; no per-level guards).
+template <typename T, int KPT, bool FULL>
+__global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_march_kernel(const AmtParams<T> p, const AmtMarchGrid g)
+{
+    extern __shared__ __align__(16) unsigned char amt_smem[];
+    const int nk = p.nk;
+    constexpr int TW = 66;                        // t_1 row buffer: 64 lanes + left/right halo
+    T *A  = reinterpret_cast<T *>(amt_smem);      // [nk][64]   dvdxi
+    T *B  = A + (size_t)nk * 64;                  // [nk][64]   ww increments
+    T *T1 = B + (size_t)nk * 64;                  // [nk][66]   t_1 of the current row j (+ i halo)
+    T *S1 = T1 + (size_t)nk * TW;                 // dnw | fnm | fnp | rdnw, nk entries each
+    const T *s_dnw = S1, *s_fnm = S1 + nk, *s_fnp = S1 + 2 * nk, *s_rdnw = S1 + 3 * nk;
+
+    const int lane = threadIdx.x & 63;
+    const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
+    const unsigned vo = (unsigned)lane * (unsigned)sizeof(T);            // the only per-lane offset
+
+    // XCD-aware logical workgroup id: blocks b, b+8, b+16 ... share an XCD (round-robin
+    // dispatch), so give each XCD a contiguous run of logical ids: neighbouring i-tiles
+    // of one j block then run on one XCD at about the same time and share the tile-edge
+    // cache lines in that XCD's L2.  Speed only, never correctness.
+    int lid;
+    {
+        const int nx = 8, q = g.nwg / nx, r = g.nwg % nx;
+        const int x = blockIdx.x % nx, y = blockIdx.x / nx;
+        lid = x * q + (x < r ? x : r) + y;        // XCD x owns q (+1 if x < r) consecutive ids
+    }
+    const int tile = g.tile_lo + lid % g.ntile_i;
+    const int jblk = lid / g.ntile_i;
+
+    for (int e = threadIdx.x; e < 4 * nk; e += blockDim.x) {
+        const int which = e / nk, k = e % nk;
+        const T *src = which == 0 ? p.dnw : which == 1 ? p.fnm : which == 2 ? p.fnp : p.rdnw;
+        S1[e] = src[p.k1 + k];
+    }
+
+    const int ii   = tile * 64 + lane;
+    const bool act = (ii >= p.i0) && (ii <= p.i1);               // column is in the window
+    const bool t1ok = (ii >= p.i0 - 1) && (ii <= p.i1 + 1);      // its t_1 is read by a window column
+    const bool edge = act && (lane == 0 || lane == 63);          // loads the tile's i halo of t_1
+    const unsigned eoff = (lane == 0) ? 0u : 2u * (unsigned)sizeof(T);   // from base-1: i-1 / i+1
+    const int ehalo = (lane == 0) ? 0 : TW - 1;                  // halo slot in a T1 row
+    const int ja   = p.j0 + jblk * g.jrows;
+    const int jb   = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
+
+    const int kf   = w * KPT;                      // my levels: zero-based kf .. kf+nlev-1
+    const int nlev = FULL ? KPT : ((nk - kf < KPT) ? (nk - kf) : KPT);
+    const bool has_above = (kf + KPT < nk);        // zero-based level kf+KPT exists
+    const long idim = p.idim, js = p.jstride;
+    const T rdx = p.rdx, rdy = p.rdy, dts = p.dts;
+    const T hrdy = T(.5) * rdy, hrdx = T(.5) * rdx;
+
+    // carried in registers from row to row (per owned level): the two j-face fluxes
+    T vfm[KPT], vft[KPT];
+#pragma unroll
+    for (int m = 0; m < KPT; ++m) { vfm[m] = vft[m] = T(0); }
+
+    // Wave-uniform base pointers (SGPR pairs), fixed for the whole march: element
+    // (lane 0 of the tile, my first level, row ja) of every 3-D array, (lane 0, row ja) of
+    // every 2-D array.  The row advance and the level step go into 32-bit per-lane byte
+    // offsets (o3, o2), which the launcher keeps below 2^31.
+    const long e3 = (long)ja * js + (long)(p.k1 + kf) * idim + (long)tile * 64;
+    const long e2 = (long)ja * idim + (long)tile * 64;
+    const T *u_b = p.u + e3, *u1_b = p.u_1 + e3, *ft_b = p.ft + e3, *ww1_b = p.ww_1 + e3;
+    const T *vn_b = p.v + e3 + js, *v1n_b = p.v_1 + e3 + js, *t1n_b = p.t_1 + e3 + js;   // row j+1
+    T *t_b = p.t + e3, *tave_b = p.t_ave + e3, *ww_b = p.ww + e3;
+    const T *wwin_b = p.ww + (long)ja * js + (long)p.k1 * idim + (long)tile * 64;          // level 1
+    const T *msftx_b = p.msftx + e2, *msfty_b = p.msfty + e2, *muu_b = p.muu + e2, *msfuy_b = p.msfuy + e2;
+    const T *muvn_b = p.muv + e2 + idim, *mvxn_b = p.msfvx_inv + e2 + idim, *mutend_b = p.mu_tend + e2;
+    const T *mut_b = p.mut + e2;
+    T *mu_b = p.mu + e2, *mudf_b = p.mudf + e2, *muts_b = p.muts + e2, *muave_b = p.muave + e2;
+    const unsigned lev = (unsigned)idim * (unsigned)sizeof(T);      // byte step of one level
+    const unsigned row3 = (unsigned)js * (unsigned)sizeof(T);       // byte step of one j row (3-D)
+    const unsigned row2 = lev;                                      // byte step of one j row (2-D)
+
+    // ---- prologue: j-face fluxes of row ja, t_1 row ja into LDS ----
+    {
+        T muv_j = T(0), mvx_j = T(0);
+        if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
+#pragma unroll
+        for (int m = 0; m < KPT; ++m) {
+            if (FULL || m < nlev) {
+                const unsigned om = vo + (unsigned)m * lev;
+                const int K = kf + m;
+                if (t1ok) {
+                    const T tc = amt_ld(p.t_1 + e3, om);
+                    T1[K * TW + 1 + lane] = tc;
+                    if (act) {
+                        const T vv = amt_ld(p.v + e3, om);
+                        vfm[m] = vv + muv_j * amt_ld(p.v_1 + e3, om) * mvx_j;
+                        vft[m] = vv * (tc + amt_ld(p.t_1 + e3 - js, om));
+                    }
+                }
+                if (edge) T1[K * TW + ehalo] = amt_ld(p.t_1 + e3 - 1, om + eoff);
+            }
+        }
+    }
+    __syncthreads();                               // S1 and T1 staged
+
+    unsigned o3 = vo, o2 = vo;                     // per-lane byte offsets of the current row
+    for (int jj = ja; jj <= jb; ++jj, o3 += row3, o2 += row2) {
+        T hf[KPT], tw[KPT], t1n[KPT], t1e[KPT];
+        T msfty = T(1), mu_tend = T(0), tw_above = T(0);
+
+        // ---------------- P1: per-cell work from pure inputs ----------------
+        if (t1ok) {
+#pragma unroll
+            for (int m = 0; m < KPT; ++m)
+                if (FULL || m < nlev) t1n[m] = amt_ld(t1n_b, o3 + (unsigned)m * lev);      // t_1(i,k,j+1)
+        }
+        if (edge) {
+#pragma unroll
+            for (int m = 0; m < KPT; ++m)
+                if (FULL || m < nlev) t1e[m] = amt_ld(t1n_b - 1, o3 + (unsigned)m * lev + eoff);
+        }
+        if (act) {
+            const T msftx = amt_ld(msftx_b, o2);
+            msfty = amt_ld(msfty_b, o2);
+            const T mm = msftx * msfty;
+            const T muu_i = amt_ld(muu_b, o2), muu_ip = amt_ld(muu_b + 1, o2);
+            const T msfuy_i = amt_ld(msfuy_b, o2), msfuy_ip = amt_ld(msfuy_b + 1, o2);
+            const T muv_p = amt_ld(muvn_b, o2), mvx_p = amt_ld(mvxn_b, o2);
+            mu_tend = amt_ld(mutend_b, o2);
+            if (has_above) {
+                // wdtn at the level above my last one needs that level's t_1 pair (:227)
+                const int Ka = kf + KPT;
+                tw_above = s_fnm[Ka] * T1[Ka * TW + 1 + lane] + s_fnp[Ka] * T1[(Ka - 1) * TW + 1 + lane];
+            }
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                if (FULL || m < nlev) {
+                    const unsigned om = o3 + (unsigned)m * lev;
+                    const int K = kf + m;
+                    const T vn = amt_ld(vn_b, om), v1n = amt_ld(v1n_b, om);
+                    const T uu = amt_ld(u_b, om), uup = amt_ld(u_b + 1, om);
+                    const T u1 = amt_ld(u1_b, om), u1p = amt_ld(u1_b + 1, om);
+                    const T t1c = T1[K * TW + 1 + lane], t1l = T1[K * TW + lane], t1r = T1[K * TW + 2 + lane];
+                    // :142-146
+                    const T vfm_n = vn + muv_p * v1n * mvx_p;
+                    const T d = mm * ( rdy * (vfm_n - vfm[m])
+                                     + rdx * ( (uup + muu_ip * u1p / msfuy_ip)
+                                             - (uu  + muu_i  * u1  / msfuy_i ) ));
+                    A[K * 64 + lane] = d;
+                    // horizontal part of :237-245
+                    const T vft_n = vn * (t1n[m] + t1c);
+                    hf[m] = msftx * ( hrdy * (vft_n - vft[m])
+                                    + hrdx * ( uup * (t1r + t1c) - uu * (t1c + t1l) ) );
+                    // fnm(k)*t_1(k) + fnp(k)*t_1(k-1) of :227 (unused for Fortran level 1)
+                    const T t1km1 = (K > 0) ? T1[(K > 0 ? K - 1 : 0) * TW + 1 + lane] : T(0);
+                    tw[m] = s_fnm[K] * t1c + s_fnp[K] * t1km1;
+                    vfm[m] = vfm_n; vft[m] = vft_n;              // the faces of row j+1
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- P2: column integral, mass update, ww increments ----------------
+        // Everybody is done with row j of t_1: install row j+1 (read again after the next barrier).
+        if (t1ok) {
+#pragma unroll
+            for (int m = 0; m < KPT; ++m)
+                if (FULL || m < nlev) T1[(kf + m) * TW + 1 + lane] = t1n[m];
+        }
+        if (edge) {
+#pragma unroll
+            for (int m = 0; m < KPT; ++m)
+                if (FULL || m < nlev) T1[(kf + m) * TW + ehalo] = t1e[m];
+        }
+        // Issue the loads that only P3 consumes now, so that the k chain below hides them.
+        T told[KPT], ftk[KPT], w1[KPT];
+        T ww1in = T(0), w1_above = T(0);
+        if (act) {
+            ww1in = amt_ld(wwin_b, o3);                           // incoming ww(i,1,j)
+            if (has_above) w1_above = amt_ld(ww1_b, o3 + (unsigned)KPT * lev);
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                if (FULL || m < nlev) {
+                    const unsigned om = o3 + (unsigned)m * lev;
+                    told[m] = amt_ld(t_b, om);
+                    ftk[m] = amt_ld(ft_b, om);
+                    w1[m] = amt_ld(ww1_b, om);
+                }
+            }
+        }
+        T dmdt = T(0);
+        for (int k = 0; k < nk; ++k)                             // :147, sequential in k
+            dmdt = dmdt + s_dnw[k] * A[k * 64 + lane];
+        if (act) {
+            // ww(i,1,j) is overwritten by wave 0 after the next barrier: make sure this wave's
+            // copy has arrived before it gets there
+            asm volatile("" : "+v"(ww1in));
+            if (w == 0) {                                        // :151-157
+                const T mu_old = amt_ld(mu_b, o2);
+                const T mu_new = mu_old + dts * (dmdt + mu_tend);
+                amt_st(mu_b, o2, mu_new);
+                amt_st(mudf_b, o2, (dmdt + mu_tend));
+                amt_st(muts_b, o2, amt_ld(mut_b, o2) + mu_new);
+                amt_st(muave_b, o2, T(.5) * ((T(1.) + p.epssm) * mu_new + (T(1.) - p.epssm) * mu_old));
+            }
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                if (FULL || m < nlev) {
+                    const int K = kf + m;
+                    B[K * 64 + lane] = s_dnw[K] * (dmdt + A[K * 64 + lane] + mu_tend) / msfty;   // :161
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- P3: ww prefix, vertical flux, theta ----------------
+        if (act) {
+            T wwu = ww1in;                                       // ww(i,1,j) of the recurrence
+            for (int k = 0; k < kf; ++k)                         // :161, sequential in k
+                wwu = wwu - B[k * 64 + lane];
+            T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];   // wdtn(i,1) = 0 (:220)
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                if (FULL || m < nlev) {
+                    const unsigned om = o3 + (unsigned)m * lev;
+                    const int K = kf + m;
+                    const T wout = wwu - w1[m];                  // :170
+                    amt_st(ww_b, om, wout);
+                    // wdtn at level K+1 (:221,:227)
+                    T wd_n = T(0);
+                    const T wwu_n = wwu - B[K * 64 + lane];
+                    if (m + 1 < KPT) {
+                        if (FULL || m + 1 < nlev) wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
+                    } else if (has_above) {
+                        wd_n = (wwu_n - w1_above) * tw_above;
+                    }
+                    amt_st(tave_b, om, told[m]);                                          // :211
+                    const T tb = told[m] + msfty * dts * ftk[m];                          // :212
+                    amt_st(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));   // :237-246
+                    wwu = wwu_n; wd_k = wd_n;
+                }
+            }
+        }
+        // no barrier needed here: A and T1 are next touched after every wave has passed this
+        // row's second barrier, B after the first barrier of the next row
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------
+static int amt_env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+template <typename T> static int amt_march_kpt(int nk)
+{
+    int kpt = amt_env_int("AMT_MARCH_KPT", 0);
+    if (kpt != 2 && kpt != 4 && kpt != 5 && kpt != 6 && kpt != 8 && kpt != 10 && kpt != 15) kpt = 0;
+    if (kpt == 0) kpt = (nk <= 32) ? 2 : (nk <= 64) ? 4 : (nk <= 128) ? 8 : 15;
+    // workgroup size is bounded by the kernel's __launch_bounds__: 16 waves (KPT < 8),
+    // 8 waves (KPT 8..10), 4 waves (KPT 15)
+    auto maxw = [](int k) { return k >= 15 ? 4 : k >= 8 ? 8 : 16; };
+    while ((nk + kpt - 1) / kpt > maxw(kpt)) {
+        kpt = kpt < 4 ? 4 : kpt < 8 ? 8 : 0;
+        if (kpt == 0) return 0;
+    }
+    return kpt;
+}
+
+template <typename T> static size_t amt_march_lds(int nk) { return ((size_t)2 * nk * 64 + (size_t)nk * 66 + 4 * (size_t)nk) * sizeof(T); }
+
+template <typename T> bool amt_march_supported(const AmtParams<T> &p)
+{
+    return p.nk >= 1 && amt_march_kpt<T>(p.nk) != 0 && amt_march_lds<T>(p.nk) <= 160 * 1024 - 1024;
+}
+
+template <typename T, int KPT, bool FULL>
+static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, size_t lds)
+{
+    const int nw = (p.nk + KPT - 1) / KPT;
+    if (lds > 64 * 1024) {
+        static thread_local size_t granted = 0;      // per kernel instantiation
+        if (lds > granted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_kernel<T, KPT, FULL>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            granted = lds;
+        }
+    }
+    hipLaunchKernelGGL((amt_march_kernel<T, KPT, FULL>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
+    return hipGetLastError();
+}
+
+template <typename T, int KPT>
+static hipError_t amt_march_launch_kpt(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, size_t lds)
+{
+    return (p.nk % KPT == 0) ? amt_march_launch_full<T, KPT, true>(stream, p, g, lds)
+                             : amt_march_launch_full<T, KPT, false>(stream, p, g, lds);
+}
+
+template <typename T>
+hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
+{
+    const int ni = p.i1 - p.i0 + 1, nj = p.j1 - p.j0 + 1;
+    if (ni <= 0 || nj <= 0) return hipSuccess;
+    const int kpt = amt_march_kpt<T>(p.nk);
+    if (kpt == 0) return hipErrorNotSupported;
+    AmtMarchGrid g;
+    g.tile_lo = p.i0 / 64;
+    g.ntile_i = p.i1 / 64 - g.tile_lo + 1;
+    int jrows = amt_env_int("AMT_MARCH_JROWS", 32);
+    if (jrows < 1) jrows = 1;
+    if (jrows > nj) jrows = nj;
+    g.jrows = jrows;
+    g.njblk = (nj + jrows - 1) / jrows;
+    g.nwg = g.ntile_i * g.njblk;
+    const size_t lds = amt_march_lds<T>(p.nk);
+    switch (kpt) {
+    case 2:  return amt_march_launch_kpt<T, 2>(stream, p, g, lds);
+    case 4:  return amt_march_launch_kpt<T, 4>(stream, p, g, lds);
+    case 5:  return amt_march_launch_kpt<T, 5>(stream, p, g, lds);
+    case 6:  return amt_march_launch_kpt<T, 6>(stream, p, g, lds);
+    case 8:  return amt_march_launch_kpt<T, 8>(stream, p, g, lds);
+    case 10: return amt_march_launch_kpt<T, 10>(stream, p, g, lds);
+    case 15: return amt_march_launch_kpt<T, 15>(stream, p, g, lds);
+    default: return hipErrorNotSupported;
+    }
+}
 
 template bool amt_march_supported<float>(const AmtParams<float> &);
 template bool amt_march_supported<double>(const AmtParams<double> &);
