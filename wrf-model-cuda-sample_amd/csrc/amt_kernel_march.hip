@@ -30,6 +30,12 @@
 #include <stdlib.h>
 #include "amt_params.h"
 
+static int amt_env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
 struct AmtMarchGrid {
     int ntile_i;     // number of 64-wide i tiles that hold window columns
     int tile_lo;     // first such tile
@@ -53,7 +59,7 @@ __device__ __forceinline__ void amt_st(T *ubase, unsigned voff, T x)
 }
 
 // FULL: nk is a multiple of KPT (every wave owns exactly KPT levels; no per-level guards).
-template <typename T, int KPT, bool FULL>
+template <typename T, int KPT, bool FULL, bool LEVEL_FENCE>
 __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_march_kernel(const AmtParams<T> p, const AmtMarchGrid g)
 {
     extern __shared__ __align__(16) unsigned char amt_smem[];
@@ -61,8 +67,9 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
     constexpr int TW = 66;                        // t_1 row buffer: 64 lanes + left/right halo
     T *A  = reinterpret_cast<T *>(amt_smem);      // [nk][64]   dvdxi
     T *B  = A + (size_t)nk * 64;                  // [nk][64]   ww increments
-    T *T1 = B + (size_t)nk * 64;                  // [nk][66]   t_1 of the current row j (+ i halo)
-    T *S1 = T1 + (size_t)nk * TW;                 // dnw | fnm | fnp | rdnw, nk entries each
+    T *T1 = B + (size_t)nk * 64;                  // [2][nk][66] t_1 of row j / row j+1 (+ i halo)
+    T *S1 = T1 + (size_t)2 * nk * TW;             // dnw | fnm | fnp | rdnw, nk entries each
+    const int t1buf = nk * TW;
     const T *s_dnw = S1, *s_fnm = S1 + nk, *s_fnp = S1 + 2 * nk, *s_rdnw = S1 + 3 * nk;
 
     const int lane = threadIdx.x & 63;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
     const unsigned row3 = (unsigned)js * (unsigned)sizeof(T);       // byte step of one j row (3-D)
     const unsigned row2 = lev;                                      // byte step of one j row (2-D)
 
-    // ---- prologue: j-face fluxes of row ja, t_1 row ja into LDS ----
+    // ---- prologue: j-face fluxes of row ja, t_1 row ja into LDS buffer 0 ----
     {
         T muv_j = T(0), mvx_j = T(0);
         if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
@@ -153,19 +160,23 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
 
     unsigned o3 = vo, o2 = vo;                     // per-lane byte offsets of the current row
     for (int jj = ja; jj <= jb; ++jj, o3 += row3, o2 += row2) {
-        T hf[KPT], tw[KPT], t1n[KPT], t1e[KPT];
+        T hf[KPT], tw[KPT];
         T msfty = T(1), mu_tend = T(0), tw_above = T(0);
+        const T *T1c = T1 + ((jj - ja) & 1) * t1buf;             // row j   (read)
+        T *T1n = T1 + (((jj - ja) & 1) ^ 1) * t1buf;             // row j+1 (written, read next row)
 
         // ---------------- P1: per-cell work from pure inputs ----------------
-        if (t1ok) {
+        if (t1ok && !act) {                                      // the (at most two) columns beside the window
 #pragma unroll
             for (int m = 0; m < KPT; ++m)
-                if (FULL || m < nlev) t1n[m] = amt_ld(t1n_b, o3 + (unsigned)m * lev);      // t_1(i,k,j+1)
+                if (FULL || m < nlev)
+                    T1n[(kf + m) * TW + 1 + lane] = amt_ld(t1n_b, o3 + (unsigned)m * lev);
         }
         if (edge) {
 #pragma unroll
             for (int m = 0; m < KPT; ++m)
-                if (FULL || m < nlev) t1e[m] = amt_ld(t1n_b - 1, o3 + (unsigned)m * lev + eoff);
+                if (FULL || m < nlev)
+                    T1n[(kf + m) * TW + ehalo] = amt_ld(t1n_b - 1, o3 + (unsigned)m * lev + eoff);
         }
         if (act) {
             const T msftx = amt_ld(msftx_b, o2);
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
             if (has_above) {
                 // wdtn at the level above my last one needs that level's t_1 pair (:227)
                 const int Ka = kf + KPT;
-                tw_above = s_fnm[Ka] * T1[Ka * TW + 1 + lane] + s_fnp[Ka] * T1[(Ka - 1) * TW + 1 + lane];
+                tw_above = s_fnm[Ka] * T1c[Ka * TW + 1 + lane] + s_fnp[Ka] * T1c[(Ka - 1) * TW + 1 + lane];
             }
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
@@ -186,9 +197,11 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                     const unsigned om = o3 + (unsigned)m * lev;
                     const int K = kf + m;
                     const T vn = amt_ld(vn_b, om), v1n = amt_ld(v1n_b, om);
+                    const T t1n = amt_ld(t1n_b, om);                       // t_1(i,k,j+1)
+                    T1n[K * TW + 1 + lane] = t1n;
                     const T uu = amt_ld(u_b, om), uup = amt_ld(u_b + 1, om);
                     const T u1 = amt_ld(u1_b, om), u1p = amt_ld(u1_b + 1, om);
-                    const T t1c = T1[K * TW + 1 + lane], t1l = T1[K * TW + lane], t1r = T1[K * TW + 2 + lane];
+                    const T t1c = T1c[K * TW + 1 + lane], t1l = T1c[K * TW + lane], t1r = T1c[K * TW + 2 + lane];
                     // :142-146
                     const T vfm_n = vn + muv_p * v1n * mvx_p;
                     const T d = mm * ( rdy * (vfm_n - vfm[m])
@@ -196,35 +209,30 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                                              - (uu  + muu_i  * u1  / msfuy_i ) ));
                     A[K * 64 + lane] = d;
                     // horizontal part of :237-245
-                    const T vft_n = vn * (t1n[m] + t1c);
+                    const T vft_n = vn * (t1n + t1c);
                     hf[m] = msftx * ( hrdy * (vft_n - vft[m])
                                     + hrdx * ( uup * (t1r + t1c) - uu * (t1c + t1l) ) );
                     // fnm(k)*t_1(k) + fnp(k)*t_1(k-1) of :227 (unused for Fortran level 1)
-                    const T t1km1 = (K > 0) ? T1[(K > 0 ? K - 1 : 0) * TW + 1 + lane] : T(0);
+                    const T t1km1 = (K > 0) ? T1c[(K > 0 ? K - 1 : 0) * TW + 1 + lane] : T(0);
                     tw[m] = s_fnm[K] * t1c + s_fnp[K] * t1km1;
                     vfm[m] = vfm_n; vft[m] = vft_n;              // the faces of row j+1
                 }
+                if (LEVEL_FENCE) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
 
         // ---------------- P2: column integral, mass update, ww increments ----------------
-        // Everybody is done with row j of t_1: install row j+1 (read again after the next barrier).
-        if (t1ok) {
-#pragma unroll
-            for (int m = 0; m < KPT; ++m)
-                if (FULL || m < nlev) T1[(kf + m) * TW + 1 + lane] = t1n[m];
-        }
-        if (edge) {
-#pragma unroll
-            for (int m = 0; m < KPT; ++m)
-                if (FULL || m < nlev) T1[(kf + m) * TW + ehalo] = t1e[m];
-        }
-        // Issue the loads that only P3 consumes now, so that the k chain below hides them.
         T told[KPT], ftk[KPT], w1[KPT];
         T ww1in = T(0), w1_above = T(0);
+        if (act) ww1in = amt_ld(wwin_b, o3);                     // incoming ww(i,1,j)
+        T dmdt = T(0);
+        for (int k = 0; k < nk; ++k)                             // :147, sequential in k
+            dmdt = dmdt + s_dnw[k] * A[k * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        // Issue the loads that only P3 consumes now: the divides below, the barrier and the
+        // ww prefix hide them (issuing them before the k chain costs 24 more live VGPRs there).
         if (act) {
-            ww1in = amt_ld(wwin_b, o3);                           // incoming ww(i,1,j)
             if (has_above) w1_above = amt_ld(ww1_b, o3 + (unsigned)KPT * lev);
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
@@ -236,9 +244,6 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                 }
             }
         }
-        T dmdt = T(0);
-        for (int k = 0; k < nk; ++k)                             // :147, sequential in k
-            dmdt = dmdt + s_dnw[k] * A[k * 64 + lane];
         if (act) {
             // ww(i,1,j) is overwritten by wave 0 after the next barrier: make sure this wave's
             // copy has arrived before it gets there
@@ -289,20 +294,14 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                 }
             }
         }
-        // no barrier needed here: A and T1 are next touched after every wave has passed this
-        // row's second barrier, B after the first barrier of the next row
+        // no barrier needed here: A and the T1 buffer written next are touched only after every
+        // wave has passed this row's second barrier, B after the first barrier of the next row
     }
 }
 
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
-static int amt_env_int(const char *name, int dflt)
-{
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
-
 template <typename T> static int amt_march_kpt(int nk)
 {
     int kpt = amt_env_int("AMT_MARCH_KPT", 0);
@@ -318,35 +317,38 @@ template <typename T> static int amt_march_kpt(int nk)
     return kpt;
 }
 
-template <typename T> static size_t amt_march_lds(int nk) { return ((size_t)2 * nk * 64 + (size_t)nk * 66 + 4 * (size_t)nk) * sizeof(T); }
+template <typename T> static size_t amt_march_lds(int nk) { return ((size_t)2 * nk * 64 + (size_t)2 * nk * 66 + 4 * (size_t)nk) * sizeof(T); }
 
 template <typename T> bool amt_march_supported(const AmtParams<T> &p)
 {
     return p.nk >= 1 && amt_march_kpt<T>(p.nk) != 0 && amt_march_lds<T>(p.nk) <= 160 * 1024 - 1024;
 }
 
-template <typename T, int KPT, bool FULL>
+template <typename T, int KPT, bool FULL, bool LEVEL_FENCE>
 static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, size_t lds)
 {
     const int nw = (p.nk + KPT - 1) / KPT;
     if (lds > 64 * 1024) {
         static thread_local size_t granted = 0;      // per kernel instantiation
         if (lds > granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_kernel<T, KPT, FULL>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_kernel<T, KPT, FULL, LEVEL_FENCE>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             granted = lds;
         }
     }
-    hipLaunchKernelGGL((amt_march_kernel<T, KPT, FULL>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
+    hipLaunchKernelGGL((amt_march_kernel<T, KPT, FULL, LEVEL_FENCE>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
     return hipGetLastError();
 }
 
 template <typename T, int KPT>
 static hipError_t amt_march_launch_kpt(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, size_t lds)
 {
-    return (p.nk % KPT == 0) ? amt_march_launch_full<T, KPT, true>(stream, p, g, lds)
-                             : amt_march_launch_full<T, KPT, false>(stream, p, g, lds);
+    static const int fence = amt_env_int("AMT_MARCH_FENCE", 0);
+    if (p.nk % KPT == 0)
+        return fence ? amt_march_launch_full<T, KPT, true, true>(stream, p, g, lds)
+                     : amt_march_launch_full<T, KPT, true, false>(stream, p, g, lds);
+    return amt_march_launch_full<T, KPT, false, false>(stream, p, g, lds);
 }
 
 template <typename T>
