@@ -302,26 +302,32 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
+// Levels per wave.  Workgroup size is bounded by the kernel's __launch_bounds__: 16 waves
+// (KPT < 8), 8 waves (KPT 8..10), 4 waves (KPT 15).  Smallest KPT that fits wins (most waves to
+// hide latency, fewest registers per lane); a KPT that divides nk is preferred (no level guards).
 template <typename T> static int amt_march_kpt(int nk)
 {
-    int kpt = amt_env_int("AMT_MARCH_KPT", 0);
-    if (kpt != 2 && kpt != 4 && kpt != 5 && kpt != 6 && kpt != 8 && kpt != 10 && kpt != 15) kpt = 0;
-    if (kpt == 0) kpt = (nk <= 32) ? 2 : (nk <= 64) ? 4 : (nk <= 128) ? 8 : 15;
-    // workgroup size is bounded by the kernel's __launch_bounds__: 16 waves (KPT < 8),
-    // 8 waves (KPT 8..10), 4 waves (KPT 15)
+    static const int cand[] = {2, 4, 5, 6, 8, 10, 15};
     auto maxw = [](int k) { return k >= 15 ? 4 : k >= 8 ? 8 : 16; };
-    while ((nk + kpt - 1) / kpt > maxw(kpt)) {
-        kpt = kpt < 4 ? 4 : kpt < 8 ? 8 : 0;
-        if (kpt == 0) return 0;
+    const int forced = amt_env_int("AMT_MARCH_KPT", 0);
+    for (int k : cand)
+        if (k == forced && (nk + k - 1) / k <= maxw(k)) return k;
+    int first_fit = 0;
+    for (int k : cand) {
+        if ((nk + k - 1) / k > maxw(k)) continue;
+        if (!first_fit) first_fit = k;
+        if (nk % k == 0 && k <= 2 * first_fit) return k;
     }
-    return kpt;
+    return first_fit;
 }
 
 template <typename T> static size_t amt_march_lds(int nk) { return ((size_t)2 * nk * 64 + (size_t)2 * nk * 66 + 4 * (size_t)nk) * sizeof(T); }
 
 template <typename T> bool amt_march_supported(const AmtParams<T> &p)
 {
-    return p.nk >= 1 && amt_march_kpt<T>(p.nk) != 0 && amt_march_lds<T>(p.nk) <= 160 * 1024 - 1024;
+    const long row_bytes = p.jstride * (long)sizeof(T);
+    const long max_rows = ((1L << 31) - 16L * p.idim * (long)sizeof(T)) / row_bytes - 3;
+    return p.nk >= 1 && amt_march_kpt<T>(p.nk) != 0 && amt_march_lds<T>(p.nk) <= 160 * 1024 - 1024 && max_rows >= 1;
 }
 
 template <typename T, int KPT, bool FULL, bool LEVEL_FENCE>
@@ -361,9 +367,19 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
     AmtMarchGrid g;
     g.tile_lo = p.i0 / 64;
     g.ntile_i = p.i1 / 64 - g.tile_lo + 1;
-    int jrows = amt_env_int("AMT_MARCH_JROWS", 32);
-    if (jrows < 1) jrows = 1;
+    // rows per workgroup: 32 amortises the per-block prologue (4 extra array-rows) to 1.6 % of
+    // the reads; small domains use shorter blocks so that at least ~512 workgroups exist
+    int jrows = amt_env_int("AMT_MARCH_JROWS", 0);
+    if (jrows < 1) {
+        const long want = ((long)nj * g.ntile_i) / 512;
+        jrows = want < 4 ? 4 : want > 32 ? 32 : (int)want;
+    }
     if (jrows > nj) jrows = nj;
+    // the per-lane byte offsets of the march are 32-bit
+    const long row_bytes = p.jstride * (long)sizeof(T);
+    const long max_rows = ((1L << 31) - 16L * p.idim * (long)sizeof(T)) / row_bytes - 3;
+    if (max_rows < 1) return hipErrorNotSupported;
+    if (jrows > max_rows) jrows = (int)max_rows;
     g.jrows = jrows;
     g.njblk = (nj + jrows - 1) / jrows;
     g.nwg = g.ntile_i * g.njblk;

@@ -1,0 +1,208 @@
+! advance_mu_t_driver.f90 -- Fortran-90 host driver of the MI355X advance_mu_t path.
+!
+! Mirrors the flow of the reference driver (advance_mu_t_driver.f90: read the
+! dimensions and the 26 arrays, time one CALL advance_mu_t, compare the 8
+! outputs), with two differences: the inputs are the seeded synthetic fields of
+! include/amt_synth.h (the reference's /data2/... dump is not shipped), and the
+! CALL goes to the drop-in module_small_step_em of this directory, i.e. through
+! ISO_C_BINDING into the HIP library.  It then repeats the sweep on the resident
+! domain handle (device arrays kept across calls -- the kernel-only time the
+! reference reports) and checks that both paths agree bit for bit.
+!
+!   advance_mu_t_driver [NI NK NJ [nsweeps [outdir [flags]]]]
+!     flags: 0 none, 1 specified, 2 nested, 3 specified+periodic_x
+!   With outdir the 7 updated arrays are written there as raw native-endian
+!   streams <name>.bin for an external checker.
+program advance_mu_t_driver
+  use iso_c_binding
+  use amt_c_binding
+  use module_configure, only : grid_config_rec_type
+  use module_small_step_em, only : advance_mu_t
+  implicit none
+
+  integer, parameter :: wp = kind(1.0)          ! default REAL: fp32, or fp64 with -fdefault-real-8
+  integer :: ni, nk, nj, nsweeps, iflag
+  integer :: ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte
+  character(len=256) :: arg, outdir
+  type(grid_config_rec_type) :: config_flags
+  real(wp), allocatable, target, dimension(:,:,:) :: ww, ww_1, u, u_1, v, v_1, t, t_1, t_ave, ft
+  real(wp), allocatable, target, dimension(:,:,:) :: ww_r, t_r, t_ave_r
+  real(wp), allocatable, target, dimension(:,:)   :: mu, mut, muave, muts, muu, muv, mudf, mu_tend
+  real(wp), allocatable, target, dimension(:,:)   :: msfuy, msfvx_inv, msftx, msfty
+  real(wp), allocatable, target, dimension(:,:)   :: mu_r, muave_r, muts_r, mudf_r
+  real(wp), allocatable, target, dimension(:)     :: dnw, fnm, fnp, rdnw
+  real(wp) :: rdx, rdy, dts, epssm
+  integer(c_int64_t), parameter :: seed = 12345_c_int64_t
+  integer(c_int) :: rc
+  type(c_ptr) :: dom
+  real(c_float) :: ms
+  integer(kind=8) :: c0, c1, hz
+  real(kind=8) :: cells, secs
+  integer :: nbad
+
+  ni = 64; nk = 40; nj = 64; nsweeps = 5; outdir = ' '; iflag = 0      ! BASELINE.json configs[0]
+  if (command_argument_count() >= 3) then
+     call get_command_argument(1, arg); read (arg, *) ni
+     call get_command_argument(2, arg); read (arg, *) nk
+     call get_command_argument(3, arg); read (arg, *) nj
+  end if
+  if (command_argument_count() >= 4) then
+     call get_command_argument(4, arg); read (arg, *) nsweeps
+  end if
+  if (command_argument_count() >= 5) call get_command_argument(5, outdir)
+  if (command_argument_count() >= 6) then
+     call get_command_argument(6, arg); read (arg, *) iflag
+  end if
+  config_flags%specified  = (iflag == 1 .or. iflag == 3)
+  config_flags%nested     = (iflag == 2)
+  config_flags%periodic_x = (iflag == 3)
+
+  ! single-patch domain, SURVEY.md section 8 convention
+  ids = 1; ide = ni + 1; jds = 1; jde = nj + 1; kde = nk + 1
+  ims = 0; ime = ni + 1; jms = 0; jme = nj + 1; kms = 1; kme = nk + 1
+  its = 1; ite = ide;    jts = 1; jte = jde;    kts = 1; kte = kde
+  rdx = 1.0e-3_wp; rdy = 1.25e-3_wp; dts = 2.0_wp; epssm = 0.1_wp      ! AMT_SYNTH_* of amt_synth.h
+
+  allocate (ww(ims:ime,kms:kme,jms:jme), ww_1(ims:ime,kms:kme,jms:jme), u(ims:ime,kms:kme,jms:jme))
+  allocate (u_1(ims:ime,kms:kme,jms:jme), v(ims:ime,kms:kme,jms:jme), v_1(ims:ime,kms:kme,jms:jme))
+  allocate (t(ims:ime,kms:kme,jms:jme), t_1(ims:ime,kms:kme,jms:jme), t_ave(ims:ime,kms:kme,jms:jme))
+  allocate (ft(ims:ime,kms:kme,jms:jme))
+  allocate (ww_r(ims:ime,kms:kme,jms:jme), t_r(ims:ime,kms:kme,jms:jme), t_ave_r(ims:ime,kms:kme,jms:jme))
+  allocate (mu(ims:ime,jms:jme), mut(ims:ime,jms:jme), muave(ims:ime,jms:jme), muts(ims:ime,jms:jme))
+  allocate (muu(ims:ime,jms:jme), muv(ims:ime,jms:jme), mudf(ims:ime,jms:jme), mu_tend(ims:ime,jms:jme))
+  allocate (msfuy(ims:ime,jms:jme), msfvx_inv(ims:ime,jms:jme), msftx(ims:ime,jms:jme), msfty(ims:ime,jms:jme))
+  allocate (mu_r(ims:ime,jms:jme), muave_r(ims:ime,jms:jme), muts_r(ims:ime,jms:jme), mudf_r(ims:ime,jms:jme))
+  allocate (dnw(kms:kme), fnm(kms:kme), fnp(kms:kme), rdnw(kms:kme))
+
+  call fill3(AMT_F_WW, ww);   call fill3(AMT_F_WW_1, ww_1); call fill3(AMT_F_U, u);   call fill3(AMT_F_U_1, u_1)
+  call fill3(AMT_F_V, v);     call fill3(AMT_F_V_1, v_1);   call fill3(AMT_F_T, t);   call fill3(AMT_F_T_1, t_1)
+  call fill3(AMT_F_T_AVE, t_ave); call fill3(AMT_F_FT, ft)
+  call fill2(AMT_F_MU, mu);   call fill2(AMT_F_MUT, mut);   call fill2(AMT_F_MUAVE, muave); call fill2(AMT_F_MUTS, muts)
+  call fill2(AMT_F_MUU, muu); call fill2(AMT_F_MUV, muv);   call fill2(AMT_F_MUDF, mudf);   call fill2(AMT_F_MU_TEND, mu_tend)
+  call fill2(AMT_F_MSFUY, msfuy); call fill2(AMT_F_MSFVX_INV, msfvx_inv)
+  call fill2(AMT_F_MSFTX, msftx); call fill2(AMT_F_MSFTY, msfty)
+  call fill1(AMT_F_DNW, dnw); call fill1(AMT_F_FNM, fnm);   call fill1(AMT_F_FNP, fnp);     call fill1(AMT_F_RDNW, rdnw)
+
+  print '(a,i0,a,i0,a,i0,a,i0,a,i0)', 'advance_mu_t ', ni, 'x', nk, 'x', nj, ' real*', storage_size(rdx)/8, &
+        '  HIP devices: ', amt_device_count()
+
+  ! ---- resident path first (it needs the un-updated inputs) ----
+  rc = amt_domain_create(dom, int(storage_size(rdx)/8, c_int),                                 &
+                         merge(1_c_int, 0_c_int, config_flags%periodic_x),                      &
+                         merge(1_c_int, 0_c_int, config_flags%specified),                       &
+                         merge(1_c_int, 0_c_int, config_flags%nested),                          &
+                         ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte)
+  call amt_check(rc, 'amt_domain_create')
+  call amt_check(amt_domain_set_scalars(dom, real(rdx, c_double), real(rdy, c_double), real(dts, c_double), &
+                                        real(epssm, c_double)), 'amt_domain_set_scalars')
+  call up(AMT_F_WW, c_loc(ww));     call up(AMT_F_WW_1, c_loc(ww_1)); call up(AMT_F_U, c_loc(u))
+  call up(AMT_F_U_1, c_loc(u_1));   call up(AMT_F_V, c_loc(v));       call up(AMT_F_V_1, c_loc(v_1))
+  call up(AMT_F_T, c_loc(t));       call up(AMT_F_T_1, c_loc(t_1));   call up(AMT_F_T_AVE, c_loc(t_ave))
+  call up(AMT_F_FT, c_loc(ft));     call up(AMT_F_MU, c_loc(mu));     call up(AMT_F_MUT, c_loc(mut))
+  call up(AMT_F_MUAVE, c_loc(muave)); call up(AMT_F_MUTS, c_loc(muts)); call up(AMT_F_MUU, c_loc(muu))
+  call up(AMT_F_MUV, c_loc(muv));   call up(AMT_F_MUDF, c_loc(mudf)); call up(AMT_F_MU_TEND, c_loc(mu_tend))
+  call up(AMT_F_MSFUY, c_loc(msfuy)); call up(AMT_F_MSFVX_INV, c_loc(msfvx_inv))
+  call up(AMT_F_MSFTX, c_loc(msftx)); call up(AMT_F_MSFTY, c_loc(msfty))
+  call up(AMT_F_DNW, c_loc(dnw));   call up(AMT_F_FNM, c_loc(fnm));   call up(AMT_F_FNP, c_loc(fnp))
+  call up(AMT_F_RDNW, c_loc(rdnw))
+  call amt_check(amt_domain_step_timed(dom, int(nsweeps, c_int), ms), 'amt_domain_step_timed')
+  cells = real(ni, 8) * real(nk, 8) * real(nj, 8)
+  print '(a,i0,a,f10.4,a,f12.1,a)', 'resident device path: ', nsweeps, ' sweeps, ', ms / nsweeps, &
+        ' ms/sweep (kernel only), ', cells * nsweeps / (ms * 1.0d-3) / 1.0d6, ' Mcells/s'
+  call dn(AMT_F_WW, c_loc(ww_r));   call dn(AMT_F_T, c_loc(t_r));     call dn(AMT_F_T_AVE, c_loc(t_ave_r))
+  call dn(AMT_F_MU, c_loc(mu_r));   call dn(AMT_F_MUAVE, c_loc(muave_r)); call dn(AMT_F_MUTS, c_loc(muts_r))
+  call dn(AMT_F_MUDF, c_loc(mudf_r))
+  call amt_check(amt_domain_destroy(dom), 'amt_domain_destroy')
+
+  ! ---- one-shot drop-in: the reference driver's CALL (advance_mu_t_driver.f90:193-205), nsweeps times ----
+  call system_clock(count_rate=hz)
+  call system_clock(count=c0)
+  block
+    integer :: s
+    do s = 1, nsweeps
+      CALL advance_mu_t( ww, ww_1, u, u_1, v, v_1,            &
+                         mu, mut, muave, muts, muu, muv,      &
+                         mudf, t, t_1,                        &
+                         t_ave, ft, mu_tend,                  &
+                         rdx, rdy, dts, epssm,                &
+                         dnw, fnm, fnp, rdnw,                 &
+                         msfuy, msfvx_inv,                    &
+                         msftx, msfty,                        &
+                         config_flags,                        &
+                         ids, ide, jds, jde, kde,             &
+                         ims, ime, jms, jme, kms, kme,        &
+                         its, ite, jts, jte, kts, kte )
+    end do
+  end block
+  call system_clock(count=c1)
+  secs = real(c1 - c0, 8) / real(hz, 8)
+  print '(a,i0,a,f10.4,a,f12.1,a)', 'one-shot host path:   ', nsweeps, ' calls,  ', secs * 1.0d3 / nsweeps, &
+        ' ms/call  (alloc+H2D+kernel+D2H), ', cells * nsweeps / secs / 1.0d6, ' Mcells/s'
+
+  ! ---- both paths must agree bit for bit ----
+  nbad = 0
+  nbad = nbad + count(transfer(ww, 1_1, size(ww) * storage_size(rdx) / 8) /= transfer(ww_r, 1_1, size(ww) * storage_size(rdx) / 8))
+  nbad = nbad + count(t /= t_r) + count(t_ave /= t_ave_r) + count(mu /= mu_r)
+  nbad = nbad + count(muave /= muave_r) + count(muts /= muts_r) + count(mudf /= mudf_r)
+  print '(a,i0)', 'one-shot vs resident: differing elements = ', nbad
+  print '(a,4es24.16)', 'checksums ww t mu muave: ', sum(real(ww, 8)), sum(real(t, 8)), sum(real(mu, 8)), sum(real(muave, 8))
+
+  if (len_trim(outdir) > 0) then
+     call dump3('ww', ww); call dump3('t', t); call dump3('t_ave', t_ave)
+     call dump2('mu', mu); call dump2('muave', muave); call dump2('muts', muts); call dump2('mudf', mudf)
+  end if
+  if (nbad /= 0) error stop 2
+
+contains
+
+  subroutine fill3(field, a)
+    integer(c_int), intent(in) :: field
+    real(wp), target, intent(inout) :: a(ims:, kms:, jms:)
+    call amt_check(amt_synth_fill_host(field, int(storage_size(rdx)/8, c_int), c_loc(a), seed,         &
+         int(ime-ims+1, c_long), int(kme-kms+1, c_long), int(jme-jms+1, c_long),                        &
+         int(ims, c_long), int(kms-1, c_long), int(jms, c_long),                                        &
+         int(ni+2, c_long), int(nk+1, c_long), int(nj+2, c_long)), 'amt_synth_fill_host')
+  end subroutine
+  subroutine fill2(field, a)
+    integer(c_int), intent(in) :: field
+    real(wp), target, intent(inout) :: a(ims:, jms:)
+    call amt_check(amt_synth_fill_host(field, int(storage_size(rdx)/8, c_int), c_loc(a), seed,         &
+         int(ime-ims+1, c_long), 1_c_long, int(jme-jms+1, c_long),                                      &
+         int(ims, c_long), 0_c_long, int(jms, c_long),                                                  &
+         int(ni+2, c_long), int(nk+1, c_long), int(nj+2, c_long)), 'amt_synth_fill_host')
+  end subroutine
+  subroutine fill1(field, a)
+    integer(c_int), intent(in) :: field
+    real(wp), target, intent(inout) :: a(kms:)
+    call amt_check(amt_synth_fill_host(field, int(storage_size(rdx)/8, c_int), c_loc(a), seed,         &
+         1_c_long, int(kme-kms+1, c_long), 1_c_long, 0_c_long, int(kms-1, c_long), 0_c_long,            &
+         int(ni+2, c_long), int(nk+1, c_long), int(nj+2, c_long)), 'amt_synth_fill_host')
+  end subroutine
+  subroutine up(field, host)
+    integer(c_int), intent(in) :: field
+    type(c_ptr), intent(in) :: host
+    call amt_check(amt_domain_upload(dom, field, host), 'amt_domain_upload')
+  end subroutine
+  subroutine dn(field, host)
+    integer(c_int), intent(in) :: field
+    type(c_ptr), intent(in) :: host
+    call amt_check(amt_domain_download(dom, field, host), 'amt_domain_download')
+  end subroutine
+  subroutine dump3(name, a)
+    character(len=*), intent(in) :: name
+    real(wp), intent(in) :: a(:,:,:)
+    integer :: un
+    open (newunit=un, file=trim(outdir)//'/'//name//'.bin', access='stream', form='unformatted', status='replace')
+    write (un) a
+    close (un)
+  end subroutine
+  subroutine dump2(name, a)
+    character(len=*), intent(in) :: name
+    real(wp), intent(in) :: a(:,:)
+    integer :: un
+    open (newunit=un, file=trim(outdir)//'/'//name//'.bin', access='stream', form='unformatted', status='replace')
+    write (un) a
+    close (un)
+  end subroutine
+
+end program advance_mu_t_driver

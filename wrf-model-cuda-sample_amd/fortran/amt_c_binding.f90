@@ -1,0 +1,147 @@
+! amt_c_binding.f90 -- ISO_C_BINDING interfaces of include/amt_advance_mu_t.h.
+!
+! Arrays cross the boundary as C addresses (c_loc of the first element): the
+! C-ABI takes plain pointers and the Fortran-style inclusive bounds unchanged.
+MODULE amt_c_binding
+   use iso_c_binding
+   implicit none
+
+   integer(c_int), parameter :: AMT_OK = 0
+
+   interface
+      ! (1) one-shot host drop-ins
+      function amt_advance_mu_t_f32(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv,    &
+                                    mudf, t, t_1, t_ave, ft, mu_tend, rdx, rdy, dts, epssm,      &
+                                    dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty,         &
+                                    periodic_x, specified, nested,                               &
+                                    ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme,       &
+                                    its, ite, jts, jte, kts, kte) bind(C, name="amt_advance_mu_t_f32") result(rc)
+         import :: c_ptr, c_float, c_int
+         type(c_ptr), value :: ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv
+         type(c_ptr), value :: mudf, t, t_1, t_ave, ft, mu_tend
+         real(c_float), value :: rdx, rdy, dts, epssm
+         type(c_ptr), value :: dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty
+         integer(c_int), value :: periodic_x, specified, nested
+         integer(c_int), value :: ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme
+         integer(c_int), value :: its, ite, jts, jte, kts, kte
+         integer(c_int) :: rc
+      end function
+      function amt_advance_mu_t_f64(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv,    &
+                                    mudf, t, t_1, t_ave, ft, mu_tend, rdx, rdy, dts, epssm,      &
+                                    dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty,         &
+                                    periodic_x, specified, nested,                               &
+                                    ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme,       &
+                                    its, ite, jts, jte, kts, kte) bind(C, name="amt_advance_mu_t_f64") result(rc)
+         import :: c_ptr, c_double, c_int
+         type(c_ptr), value :: ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv
+         type(c_ptr), value :: mudf, t, t_1, t_ave, ft, mu_tend
+         real(c_double), value :: rdx, rdy, dts, epssm
+         type(c_ptr), value :: dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty
+         integer(c_int), value :: periodic_x, specified, nested
+         integer(c_int), value :: ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme
+         integer(c_int), value :: its, ite, jts, jte, kts, kte
+         integer(c_int) :: rc
+      end function
+
+      ! error text of the calling thread (NUL-terminated C string)
+      function amt_last_error() bind(C, name="amt_last_error") result(msg)
+         import :: c_ptr
+         type(c_ptr) :: msg
+      end function
+      function amt_device_count() bind(C, name="amt_device_count") result(n)
+         import :: c_int
+         integer(c_int) :: n
+      end function
+
+      ! (3) resident domain handle
+      function amt_domain_create(handle, dtype_bytes, periodic_x, specified, nested,             &
+                                 ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme,          &
+                                 its, ite, jts, jte, kts, kte) bind(C, name="amt_domain_create") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr) :: handle                      ! amt_domain **
+         integer(c_int), value :: dtype_bytes, periodic_x, specified, nested
+         integer(c_int), value :: ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme
+         integer(c_int), value :: its, ite, jts, jte, kts, kte
+         integer(c_int) :: rc
+      end function
+      function amt_domain_destroy(handle) bind(C, name="amt_domain_destroy") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: handle
+         integer(c_int) :: rc
+      end function
+      function amt_domain_set_scalars(handle, rdx, rdy, dts, epssm) bind(C, name="amt_domain_set_scalars") result(rc)
+         import :: c_ptr, c_int, c_double
+         type(c_ptr), value :: handle
+         real(c_double), value :: rdx, rdy, dts, epssm
+         integer(c_int) :: rc
+      end function
+      function amt_domain_upload(handle, field, host) bind(C, name="amt_domain_upload") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: handle, host
+         integer(c_int), value :: field
+         integer(c_int) :: rc
+      end function
+      function amt_domain_download(handle, field, host) bind(C, name="amt_domain_download") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: handle, host
+         integer(c_int), value :: field
+         integer(c_int) :: rc
+      end function
+      function amt_domain_step(handle, n_sweeps) bind(C, name="amt_domain_step") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: handle
+         integer(c_int), value :: n_sweeps
+         integer(c_int) :: rc
+      end function
+      function amt_domain_step_timed(handle, n_sweeps, ms_total) bind(C, name="amt_domain_step_timed") result(rc)
+         import :: c_ptr, c_int, c_float
+         type(c_ptr), value :: handle
+         integer(c_int), value :: n_sweeps
+         real(c_float) :: ms_total
+         integer(c_int) :: rc
+      end function
+      function amt_domain_sync(handle) bind(C, name="amt_domain_sync") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: handle
+         integer(c_int) :: rc
+      end function
+
+      ! (4) synthetic inputs
+      function amt_synth_fill_host(field, dtype_bytes, dst, seed, idim, kdim, jdim, gi0, gk0, gj0, &
+                                   gidim, gkdim, gjdim) bind(C, name="amt_synth_fill_host") result(rc)
+         import :: c_ptr, c_int, c_long, c_int64_t
+         integer(c_int), value :: field, dtype_bytes
+         type(c_ptr), value :: dst
+         integer(c_int64_t), value :: seed
+         integer(c_long), value :: idim, kdim, jdim, gi0, gk0, gj0, gidim, gkdim, gjdim
+         integer(c_int) :: rc
+      end function
+   end interface
+
+   ! enum amt_field (include/amt_synth.h): the Fortran argument order
+   integer(c_int), parameter :: AMT_F_WW = 0, AMT_F_WW_1 = 1, AMT_F_U = 2, AMT_F_U_1 = 3, AMT_F_V = 4,      &
+      AMT_F_V_1 = 5, AMT_F_MU = 6, AMT_F_MUT = 7, AMT_F_MUAVE = 8, AMT_F_MUTS = 9, AMT_F_MUU = 10,          &
+      AMT_F_MUV = 11, AMT_F_MUDF = 12, AMT_F_T = 13, AMT_F_T_1 = 14, AMT_F_T_AVE = 15, AMT_F_FT = 16,       &
+      AMT_F_MU_TEND = 17, AMT_F_DNW = 18, AMT_F_FNM = 19, AMT_F_FNP = 20, AMT_F_RDNW = 21,                  &
+      AMT_F_MSFUY = 22, AMT_F_MSFVX_INV = 23, AMT_F_MSFTX = 24, AMT_F_MSFTY = 25
+
+CONTAINS
+
+   subroutine amt_check(rc, what)
+      integer(c_int), intent(in) :: rc
+      character(len=*), intent(in) :: what
+      character(kind=c_char), pointer :: cmsg(:)
+      character(len=512) :: msg
+      integer :: n
+      if (rc == AMT_OK) return
+      call c_f_pointer(amt_last_error(), cmsg, [512])
+      msg = ' '
+      do n = 1, 512
+         if (cmsg(n) == c_null_char) exit
+         msg(n:n) = cmsg(n)
+      end do
+      write (*, '(a,a,a,i0,a,a)') 'amt: ', what, ' failed with status ', rc, ': ', trim(msg)
+      error stop 1
+   end subroutine amt_check
+
+END MODULE amt_c_binding
