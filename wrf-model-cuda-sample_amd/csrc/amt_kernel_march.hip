@@ -36,6 +36,13 @@ static int amt_env_int(const char *name, int dflt)
     return (s && *s) ? atoi(s) : dflt;
 }
 
+#ifndef AMT_PF_U
+#define AMT_PF_U 0      /* 1: also prefetch u, u_1 of the next row (costs 4*KPT more VGPRs in fp64) */
+#endif
+#ifndef AMT_CHAIN
+#define AMT_CHAIN 4     /* LDS reads kept in flight by the sequential k chains */
+#endif
+
 struct AmtMarchGrid {
     int ntile_i;     // number of 64-wide i tiles that hold window columns
     int tile_lo;     // first such tile
@@ -59,21 +66,25 @@ __device__ __forceinline__ void amt_st(T *ubase, unsigned voff, T x)
 }
 
 // FULL: nk is a multiple of KPT (every wave owns exactly KPT levels; no per-level guards).
-template <typename T, int KPT, bool FULL, bool LEVEL_FENCE>
+// PF:   prefetch v, v_1, t_1 of the next row under P3 (3*KPT more live values); else load in P1.
+template <typename T, int KPT, bool FULL, bool PF>
 __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_march_kernel(const AmtParams<T> p, const AmtMarchGrid g)
 {
     extern __shared__ __align__(16) unsigned char amt_smem[];
     const int nk = p.nk;
-    constexpr int TW = 66;                        // t_1 row buffer: 64 lanes + left/right halo
-    T *A  = reinterpret_cast<T *>(amt_smem);      // [nk][64]   dvdxi
-    T *B  = A + (size_t)nk * 64;                  // [nk][64]   ww increments
+    constexpr int TW = 66;                        // row buffers: 64 lanes + left/right halo
+    constexpr int N2D = 7;                        // staged 2-D rows: msftx msfty muu msfuy muv' msfvx_inv' mu_tend
+    T *AP = reinterpret_cast<T *>(amt_smem);      // [nk][64]   dnw(k)*dvdxi(i,k)  (the terms of dmdt)
+    T *B  = AP + (size_t)nk * 64;                 // [nk][64]   ww increments
     T *T1 = B + (size_t)nk * 64;                  // [2][nk][66] t_1 of row j / row j+1 (+ i halo)
-    T *S1 = T1 + (size_t)2 * nk * TW;             // dnw | fnm | fnp | rdnw, nk entries each
-    const int t1buf = nk * TW;
+    T *D2 = T1 + (size_t)2 * nk * TW;             // [2][N2D][66] 2-D inputs of row j / row j+1
+    T *S1 = D2 + (size_t)2 * N2D * TW;            // dnw | fnm | fnp | rdnw, nk entries each
     const T *s_dnw = S1, *s_fnm = S1 + nk, *s_fnp = S1 + 2 * nk, *s_rdnw = S1 + 3 * nk;
+    const int t1buf = nk * TW, d2buf = N2D * TW;
 
     const int lane = threadIdx.x & 63;
     const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
+    const int nwav = (int)(blockDim.x >> 6);
     const unsigned vo = (unsigned)lane * (unsigned)sizeof(T);            // the only per-lane offset
 
     // XCD-aware logical workgroup id: blocks b, b+8, b+16 ... share an XCD (round-robin
@@ -99,8 +110,10 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
     const bool act = (ii >= p.i0) && (ii <= p.i1);               // column is in the window
     const bool t1ok = (ii >= p.i0 - 1) && (ii <= p.i1 + 1);      // its t_1 is read by a window column
     const bool edge = act && (lane == 0 || lane == 63);          // loads the tile's i halo of t_1
+    const bool inmem = ii < p.idim;                              // lane is inside the memory row
+    const bool halo_r = (lane == 0) && (ii + 64 < p.idim);       // lane 0 also fetches element i+64
     const unsigned eoff = (lane == 0) ? 0u : 2u * (unsigned)sizeof(T);   // from base-1: i-1 / i+1
-    const int ehalo = (lane == 0) ? 0 : TW - 1;                  // halo slot in a T1 row
+    const int ehalo = (lane == 0) ? 0 : TW - 1;                  // halo slot in a row buffer
     const int ja   = p.j0 + jblk * g.jrows;
     const int jb   = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
 
@@ -110,11 +123,6 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
     const long idim = p.idim, js = p.jstride;
     const T rdx = p.rdx, rdy = p.rdy, dts = p.dts;
     const T hrdy = T(.5) * rdy, hrdx = T(.5) * rdx;
-
-    // carried in registers from row to row (per owned level): the two j-face fluxes
-    T vfm[KPT], vft[KPT];
-#pragma unroll
-    for (int m = 0; m < KPT; ++m) { vfm[m] = vft[m] = T(0); }
 
     // Wave-uniform base pointers (SGPR pairs), fixed for the whole march: element
     // (lane 0 of the tile, my first level, row ja) of every 3-D array, (lane 0, row ja) of
@@ -126,18 +134,44 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
     const T *vn_b = p.v + e3 + js, *v1n_b = p.v_1 + e3 + js, *t1n_b = p.t_1 + e3 + js;   // row j+1
     T *t_b = p.t + e3, *tave_b = p.t_ave + e3, *ww_b = p.ww + e3;
     const T *wwin_b = p.ww + (long)ja * js + (long)p.k1 * idim + (long)tile * 64;          // level 1
-    const T *msftx_b = p.msftx + e2, *msfty_b = p.msfty + e2, *muu_b = p.muu + e2, *msfuy_b = p.msfuy + e2;
-    const T *muvn_b = p.muv + e2 + idim, *mvxn_b = p.msfvx_inv + e2 + idim, *mutend_b = p.mu_tend + e2;
     const T *mut_b = p.mut + e2;
     T *mu_b = p.mu + e2, *mudf_b = p.mudf + e2, *muts_b = p.muts + e2, *muave_b = p.muave + e2;
     const unsigned lev = (unsigned)idim * (unsigned)sizeof(T);      // byte step of one level
     const unsigned row3 = (unsigned)js * (unsigned)sizeof(T);       // byte step of one j row (3-D)
     const unsigned row2 = lev;                                      // byte step of one j row (2-D)
 
-    // ---- prologue: j-face fluxes of row ja, t_1 row ja into LDS buffer 0 ----
+    // The 2-D inputs of a row are fetched ONCE per workgroup (wave q fetches array q, q+nwav, ...)
+    // one row ahead and handed to the other waves through LDS.  Slot order of D2:
+    //   0 msftx(j) 1 msfty(j) 2 muu(j) 3 msfuy(j) 4 muv(j+1) 5 msfvx_inv(j+1) 6 mu_tend(j)
+    auto d2_src = [&](int q) -> const T * {
+        switch (q) {
+        case 0: return p.msftx + e2;
+        case 1: return p.msfty + e2;
+        case 2: return p.muu + e2;
+        case 3: return p.msfuy + e2;
+        case 4: return p.muv + e2 + idim;
+        case 5: return p.msfvx_inv + e2 + idim;
+        default: return p.mu_tend + e2;
+        }
+    };
+
+    // carried in registers from row to row (per owned level): the two j-face fluxes,
+    // and the prefetched inputs of the next row's P1
+    T vfm[KPT], vft[KPT];
+    T pv[KPT], pv1[KPT], pt1[KPT], pu[AMT_PF_U ? KPT : 1], pu1[AMT_PF_U ? KPT : 1];
+#pragma unroll
+    for (int m = 0; m < KPT; ++m) { vfm[m] = vft[m] = pv[m] = pv1[m] = pt1[m] = T(0); if (AMT_PF_U) pu[m] = pu1[m] = T(0); }
+
+    // ---- prologue: j-face fluxes of row ja, t_1 row ja and the 2-D row ja into LDS buffer 0,
+    //      first prefetch ----
     {
         T muv_j = T(0), mvx_j = T(0);
         if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
+        for (int q = w; q < N2D; q += nwav) {
+            const T *src = d2_src(q);
+            if (inmem) D2[q * TW + 1 + lane] = amt_ld(src, vo);
+            if (halo_r) D2[q * TW + TW - 1] = amt_ld(src + 64, vo);
+        }
 #pragma unroll
         for (int m = 0; m < KPT; ++m) {
             if (FULL || m < nlev) {
@@ -150,27 +184,36 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                         const T vv = amt_ld(p.v + e3, om);
                         vfm[m] = vv + muv_j * amt_ld(p.v_1 + e3, om) * mvx_j;
                         vft[m] = vv * (tc + amt_ld(p.t_1 + e3 - js, om));
+                        if (PF) { pv[m] = amt_ld(vn_b, om); pv1[m] = amt_ld(v1n_b, om); }
+                        if (AMT_PF_U) { pu[m] = amt_ld(u_b, om);  pu1[m] = amt_ld(u1_b, om); }
                     }
+                    if (PF) pt1[m] = amt_ld(t1n_b, om);
                 }
                 if (edge) T1[K * TW + ehalo] = amt_ld(p.t_1 + e3 - 1, om + eoff);
             }
         }
     }
-    __syncthreads();                               // S1 and T1 staged
+    __syncthreads();                               // S1, T1[0], D2[0] staged
 
     unsigned o3 = vo, o2 = vo;                     // per-lane byte offsets of the current row
     for (int jj = ja; jj <= jb; ++jj, o3 += row3, o2 += row2) {
-        T hf[KPT], tw[KPT];
+        T hf[KPT], tw[KPT], dv[KPT];
         T msfty = T(1), mu_tend = T(0), tw_above = T(0);
-        const T *T1c = T1 + ((jj - ja) & 1) * t1buf;             // row j   (read)
-        T *T1n = T1 + (((jj - ja) & 1) ^ 1) * t1buf;             // row j+1 (written, read next row)
+        const int par = (jj - ja) & 1;
+        const T *T1c = T1 + par * t1buf;                         // t_1 row j   (read)
+        T *T1n = T1 + (par ^ 1) * t1buf;                         // t_1 row j+1 (written, read next row)
+        const T *D2c = D2 + par * d2buf;                         // 2-D row j   (read)
+        T *D2n = D2 + (par ^ 1) * d2buf;                         // 2-D row j+1 (written in P2)
+        const bool more = (jj < jb);                             // another row follows in this block
 
         // ---------------- P1: per-cell work from pure inputs ----------------
-        if (t1ok && !act) {                                      // the (at most two) columns beside the window
+        if (t1ok) {
 #pragma unroll
             for (int m = 0; m < KPT; ++m)
-                if (FULL || m < nlev)
-                    T1n[(kf + m) * TW + 1 + lane] = amt_ld(t1n_b, o3 + (unsigned)m * lev);
+                if (FULL || m < nlev) {
+                    if (!PF) pt1[m] = amt_ld(t1n_b, o3 + (unsigned)m * lev);
+                    T1n[(kf + m) * TW + 1 + lane] = pt1[m];                         // t_1(i,k,j+1)
+                }
         }
         if (edge) {
 #pragma unroll
@@ -179,13 +222,13 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                     T1n[(kf + m) * TW + ehalo] = amt_ld(t1n_b - 1, o3 + (unsigned)m * lev + eoff);
         }
         if (act) {
-            const T msftx = amt_ld(msftx_b, o2);
-            msfty = amt_ld(msfty_b, o2);
+            const T msftx = D2c[0 * TW + 1 + lane];
+            msfty = D2c[1 * TW + 1 + lane];
             const T mm = msftx * msfty;
-            const T muu_i = amt_ld(muu_b, o2), muu_ip = amt_ld(muu_b + 1, o2);
-            const T msfuy_i = amt_ld(msfuy_b, o2), msfuy_ip = amt_ld(msfuy_b + 1, o2);
-            const T muv_p = amt_ld(muvn_b, o2), mvx_p = amt_ld(mvxn_b, o2);
-            mu_tend = amt_ld(mutend_b, o2);
+            const T muu_i = D2c[2 * TW + 1 + lane], muu_ip = D2c[2 * TW + 2 + lane];
+            const T msfuy_i = D2c[3 * TW + 1 + lane], msfuy_ip = D2c[3 * TW + 2 + lane];
+            const T muv_p = D2c[4 * TW + 1 + lane], mvx_p = D2c[5 * TW + 1 + lane];
+            mu_tend = D2c[6 * TW + 1 + lane];
             if (has_above) {
                 // wdtn at the level above my last one needs that level's t_1 pair (:227)
                 const int Ka = kf + KPT;
@@ -196,18 +239,17 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                 if (FULL || m < nlev) {
                     const unsigned om = o3 + (unsigned)m * lev;
                     const int K = kf + m;
-                    const T vn = amt_ld(vn_b, om), v1n = amt_ld(v1n_b, om);
-                    const T t1n = amt_ld(t1n_b, om);                       // t_1(i,k,j+1)
-                    T1n[K * TW + 1 + lane] = t1n;
-                    const T uu = amt_ld(u_b, om), uup = amt_ld(u_b + 1, om);
-                    const T u1 = amt_ld(u1_b, om), u1p = amt_ld(u1_b + 1, om);
+                    const T uup = amt_ld(u_b + 1, om), u1p = amt_ld(u1_b + 1, om);   // same lines as pu/pu1
+                    const T vn = PF ? pv[m] : amt_ld(vn_b, om), v1n = PF ? pv1[m] : amt_ld(v1n_b, om), t1n = pt1[m];
+                    const T uu = AMT_PF_U ? pu[m] : amt_ld(u_b, om), u1 = AMT_PF_U ? pu1[m] : amt_ld(u1_b, om);
                     const T t1c = T1c[K * TW + 1 + lane], t1l = T1c[K * TW + lane], t1r = T1c[K * TW + 2 + lane];
                     // :142-146
                     const T vfm_n = vn + muv_p * v1n * mvx_p;
                     const T d = mm * ( rdy * (vfm_n - vfm[m])
                                      + rdx * ( (uup + muu_ip * u1p / msfuy_ip)
                                              - (uu  + muu_i  * u1  / msfuy_i ) ));
-                    A[K * 64 + lane] = d;
+                    dv[m] = d;
+                    AP[K * 64 + lane] = s_dnw[K] * d;            // the term of :147
                     // horizontal part of :237-245
                     const T vft_n = vn * (t1n + t1c);
                     hf[m] = msftx * ( hrdy * (vft_n - vft[m])
@@ -217,22 +259,50 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                     tw[m] = s_fnm[K] * t1c + s_fnp[K] * t1km1;
                     vfm[m] = vfm_n; vft[m] = vft_n;              // the faces of row j+1
                 }
-                if (LEVEL_FENCE) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
 
         // ---------------- P2: column integral, mass update, ww increments ----------------
-        T told[KPT], ftk[KPT], w1[KPT];
-        T ww1in = T(0), w1_above = T(0);
-        if (act) ww1in = amt_ld(wwin_b, o3);                     // incoming ww(i,1,j)
-        T dmdt = T(0);
-        for (int k = 0; k < nk; ++k)                             // :147, sequential in k
-            dmdt = dmdt + s_dnw[k] * A[k * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);
-        // Issue the loads that only P3 consumes now: the divides below, the barrier and the
-        // ww prefix hide them (issuing them before the k chain costs 24 more live VGPRs there).
+        // fetch the next row's 2-D inputs (one array per wave) and what only P3 consumes; the
+        // k chain below hides the latency
+        T d2v = T(0), d2h = T(0);
+        int d2q = -1;
+        if (more) {
+            for (int q = w; q < N2D; q += nwav) {                // at most one pass when nwav >= 7
+                if (d2q >= 0) {                                  // (rare: fewer than 7 waves) flush the previous one
+                    if (inmem) D2n[d2q * TW + 1 + lane] = d2v;
+                    if (halo_r) D2n[d2q * TW + TW - 1] = d2h;
+                }
+                const T *src = d2_src(q);
+                if (inmem) d2v = amt_ld(src, o2 + row2);
+                if (halo_r) d2h = amt_ld(src + 64, o2 + row2);
+                d2q = q;
+            }
+        }
+        T ww1in = T(0), mu_old = T(0), mut_v = T(0);
         if (act) {
+            ww1in = amt_ld(wwin_b, o3);                          // incoming ww(i,1,j)
+            if (w == 0) { mu_old = amt_ld(mu_b, o2); mut_v = amt_ld(mut_b, o2); }
+        }
+        T dmdt = T(0);
+        {                                                        // :147, sequential in k
+            int k = 0;
+            for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
+                T a[AMT_CHAIN];
+#pragma unroll
+                for (int q = 0; q < AMT_CHAIN; ++q) a[q] = AP[(k + q) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < AMT_CHAIN; ++q) dmdt = dmdt + a[q];
+            }
+            for (; k < nk; ++k) dmdt = dmdt + AP[k * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        T told[KPT], ftk[KPT], w1[KPT];
+        T w1_above = T(0);
+        if (act) {
+            // issue the loads that only P3 consumes: the divides below, the barrier and the ww
+            // prefix hide them (issuing them before the k chain costs 24 more live VGPRs there)
             if (has_above) w1_above = amt_ld(ww1_b, o3 + (unsigned)KPT * lev);
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
@@ -243,34 +313,58 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                     w1[m] = amt_ld(ww1_b, om);
                 }
             }
-        }
-        if (act) {
             // ww(i,1,j) is overwritten by wave 0 after the next barrier: make sure this wave's
             // copy has arrived before it gets there
             asm volatile("" : "+v"(ww1in));
             if (w == 0) {                                        // :151-157
-                const T mu_old = amt_ld(mu_b, o2);
                 const T mu_new = mu_old + dts * (dmdt + mu_tend);
                 amt_st(mu_b, o2, mu_new);
                 amt_st(mudf_b, o2, (dmdt + mu_tend));
-                amt_st(muts_b, o2, amt_ld(mut_b, o2) + mu_new);
+                amt_st(muts_b, o2, mut_v + mu_new);
                 amt_st(muave_b, o2, T(.5) * ((T(1.) + p.epssm) * mu_new + (T(1.) - p.epssm) * mu_old));
             }
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
                 if (FULL || m < nlev) {
                     const int K = kf + m;
-                    B[K * 64 + lane] = s_dnw[K] * (dmdt + A[K * 64 + lane] + mu_tend) / msfty;   // :161
+                    B[K * 64 + lane] = s_dnw[K] * (dmdt + dv[m] + mu_tend) / msfty;   // :161
                 }
             }
+        }
+        if (d2q >= 0) {                                          // hand the 2-D row j+1 to everybody
+            if (inmem) D2n[d2q * TW + 1 + lane] = d2v;
+            if (halo_r) D2n[d2q * TW + TW - 1] = d2h;
         }
         __syncthreads();
 
         // ---------------- P3: ww prefix, vertical flux, theta ----------------
+        // prefetch the inputs of the next row's P1 under the prefix chain and the stores
+        if (PF && more) {
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                if (FULL || m < nlev) {
+                    const unsigned om = o3 + row3 + (unsigned)m * lev;
+                    if (act) {
+                        pv[m] = amt_ld(vn_b, om); pv1[m] = amt_ld(v1n_b, om);
+                        if (AMT_PF_U) { pu[m] = amt_ld(u_b, om);  pu1[m] = amt_ld(u1_b, om); }
+                    }
+                    if (t1ok) pt1[m] = amt_ld(t1n_b, om);
+                }
+            }
+        }
         if (act) {
             T wwu = ww1in;                                       // ww(i,1,j) of the recurrence
-            for (int k = 0; k < kf; ++k)                         // :161, sequential in k
-                wwu = wwu - B[k * 64 + lane];
+            {                                                    // :161, sequential in k
+                int k = 0;
+                for (; k + AMT_CHAIN <= kf; k += AMT_CHAIN) {
+                    T b[AMT_CHAIN];
+#pragma unroll
+                    for (int q = 0; q < AMT_CHAIN; ++q) b[q] = B[(k + q) * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < AMT_CHAIN; ++q) wwu = wwu - b[q];
+                }
+                for (; k < kf; ++k) wwu = wwu - B[k * 64 + lane];
+            }
             T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];   // wdtn(i,1) = 0 (:220)
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
@@ -294,8 +388,8 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
                 }
             }
         }
-        // no barrier needed here: A and the T1 buffer written next are touched only after every
-        // wave has passed this row's second barrier, B after the first barrier of the next row
+        // no barrier needed here: AP and the T1/D2 buffers written next are touched only after
+        // every wave has passed this row's second barrier, B after the first barrier of the next row
     }
 }
 
@@ -321,7 +415,7 @@ template <typename T> static int amt_march_kpt(int nk)
     return first_fit;
 }
 
-template <typename T> static size_t amt_march_lds(int nk) { return ((size_t)2 * nk * 64 + (size_t)2 * nk * 66 + 4 * (size_t)nk) * sizeof(T); }
+template <typename T> static size_t amt_march_lds(int nk) { return ((size_t)2 * nk * 64 + (size_t)2 * nk * 66 + 2 * 7 * 66 + 4 * (size_t)nk) * sizeof(T); }
 
 template <typename T> bool amt_march_supported(const AmtParams<T> &p)
 {
@@ -330,30 +424,31 @@ template <typename T> bool amt_march_supported(const AmtParams<T> &p)
     return p.nk >= 1 && amt_march_kpt<T>(p.nk) != 0 && amt_march_lds<T>(p.nk) <= 160 * 1024 - 1024 && max_rows >= 1;
 }
 
-template <typename T, int KPT, bool FULL, bool LEVEL_FENCE>
+template <typename T, int KPT, bool FULL, bool PF>
 static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, size_t lds)
 {
     const int nw = (p.nk + KPT - 1) / KPT;
     if (lds > 64 * 1024) {
         static thread_local size_t granted = 0;      // per kernel instantiation
         if (lds > granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_kernel<T, KPT, FULL, LEVEL_FENCE>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_kernel<T, KPT, FULL, PF>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             granted = lds;
         }
     }
-    hipLaunchKernelGGL((amt_march_kernel<T, KPT, FULL, LEVEL_FENCE>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
+    hipLaunchKernelGGL((amt_march_kernel<T, KPT, FULL, PF>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
     return hipGetLastError();
 }
 
 template <typename T, int KPT>
 static hipError_t amt_march_launch_kpt(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, size_t lds)
 {
-    static const int fence = amt_env_int("AMT_MARCH_FENCE", 0);
+    // prefetching costs 3*KPT live values: worth it where registers allow (fp32), not in fp64 at KPT 4
+    static const int pf = amt_env_int("AMT_MARCH_PF", sizeof(T) == 4 ? 1 : 0);
     if (p.nk % KPT == 0)
-        return fence ? amt_march_launch_full<T, KPT, true, true>(stream, p, g, lds)
-                     : amt_march_launch_full<T, KPT, true, false>(stream, p, g, lds);
+        return pf ? amt_march_launch_full<T, KPT, true, true>(stream, p, g, lds)
+                  : amt_march_launch_full<T, KPT, true, false>(stream, p, g, lds);
     return amt_march_launch_full<T, KPT, false, false>(stream, p, g, lds);
 }
 
