@@ -6,27 +6,36 @@
 //
 //  * A workgroup owns one 64-wide i-tile (memory aligned), ALL levels, and a block
 //    of consecutive j rows that it marches through.  Lane = i (so every 3-D access
-//    of a wave is one contiguous 64*sizeof(T) run: i-contiguous coalesced loads);
-//    wave w owns the KPT consecutive levels w*KPT+1 .. (w+1)*KPT.
+//    of a wave is one contiguous 64*sizeof(T) run: i-contiguous coalesced loads).
+//    NC "cell" waves own KPT consecutive levels each (wave w: levels w*KPT+1 .. (w+1)*KPT);
+//    one more "column" wave owns everything that is per column (i,j) rather than per
+//    cell: the two sequential k chains, the 2-D mass update, and the staging of the
+//    2-D input rows (wave specialisation; 15 + 1 waves for NK = 60).
 //  * The j-direction face fluxes  v(j)+muv(j)*v_1(j)*msfvx_inv(j)  and
-//    v(j)*(t_1(j)+t_1(j-1))  and the t_1 row itself are carried in registers from
-//    one row to the next (the face j+1 of row j IS the face j of row j+1: the same
-//    expression on the same operands, so carrying it is bit-exact).
-//  * The three k-dependencies go through LDS (k-column staging):
-//      A[k][lane] = dvdxi(i,k)   -> every wave sums the column in the Fortran's
-//                                   sequential k order (dmdt), bit-exact
-//      B[k][lane] = dnw(k)*(dmdt+dvdxi(k)+mu_tend)/msfty  (the ww increment; one divide
-//                                   per cell, computed once by the wave owning the level)
-//                                -> every wave runs the sequential prefix
-//                                   ww(k+1) = ww(k) - B[k] up to its own levels
-//    wdtn(k+1) across a wave boundary is recomputed from one extra ww_1/t_1 level.
-//    Two workgroup barriers per j row.
+//    v(j)*(t_1(j)+t_1(j-1))  are carried in registers from one row to the next (the face
+//    j+1 of row j IS the face j of row j+1: the same expression on the same operands,
+//    so carrying it is bit-exact); the t_1 row is carried in LDS (with its i halo), which
+//    also serves t_1(i-1), t_1(i+1) and t_1(k-1).  v, v_1, t_1 are read once.
+//  * The k-dependencies go through LDS (k-column staging), four barriers per j row:
+//      cell waves   AP[k][lane] = dnw(k)*dvdxi(i,k)                        (:142-147)
+//      -- barrier 1 --
+//      column wave  dmdt = sum_k AP[k] in the Fortran's sequential k order -> DM[lane]
+//      -- barrier 2 --
+//      cell waves   B[k][lane] = dnw(k)*(dmdt+dvdxi(k)+mu_tend)/msfty  (:161, one divide
+//                   per cell); column wave: the 2-D mass update (:151-157)
+//      -- barrier 3 --
+//      column wave  ww(k+1) = ww(k) - B[k], sequential, written back into B  (:161)
+//      -- barrier 4 --
+//      cell waves   ww - ww_1 (:170), wdtn (:220-227), theta update (:211-212, :237-246)
+//    A column's chains are summed exactly once, in order: bit-exact and no redundant LDS
+//    traffic (an earlier version let every wave redo both chains: LDS-bandwidth bound).
 //  * Expressions keep the Fortran association; built with -ffp-contract=off.
 //
 // Reference semantics: module_small_step_em.f90:112-172 (mu, ww), :208-215 and
 // :217-250 (theta); the fusion of the three Fortran phases is legal because a
 // column never reads another column's outputs.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "amt_params.h"
 
@@ -36,11 +45,8 @@ static int amt_env_int(const char *name, int dflt)
     return (s && *s) ? atoi(s) : dflt;
 }
 
-#ifndef AMT_PF_U
-#define AMT_PF_U 0      /* 1: also prefetch u, u_1 of the next row (costs 4*KPT more VGPRs in fp64) */
-#endif
 #ifndef AMT_CHAIN
-#define AMT_CHAIN 4     /* LDS reads kept in flight by the sequential k chains */
+#define AMT_CHAIN 10    /* LDS reads kept in flight by the sequential k chains */
 #endif
 
 struct AmtMarchGrid {
@@ -49,6 +55,7 @@ struct AmtMarchGrid {
     int jrows;       // rows per workgroup
     int njblk;       // number of j blocks
     int nwg;         // ntile_i * njblk
+    unsigned long long *stamps;   // diagnostic instantiation only: 8 cycle sums per wave
 };
 
 // Uniform-base addressing: every global access is  (wave-uniform pointer in SGPRs) +
@@ -65,27 +72,43 @@ __device__ __forceinline__ void amt_st(T *ubase, unsigned voff, T x)
     *reinterpret_cast<T *>(reinterpret_cast<char *>(ubase) + voff) = x;
 }
 
-// FULL: nk is a multiple of KPT (every wave owns exactly KPT levels; no per-level guards).
-// PF:   prefetch v, v_1, t_1 of the next row under P3 (3*KPT more live values); else load in P1.
-template <typename T, int KPT, bool FULL, bool PF>
-__global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_march_kernel(const AmtParams<T> p, const AmtMarchGrid g)
+constexpr int AMT_TW = 66;    // LDS row buffers: 64 lanes + left/right halo
+constexpr int AMT_N2D = 7;    // staged 2-D rows: msftx msfty muu msfuy muv' msfvx_inv' mu_tend
+
+// FULL: nk is a multiple of KPT (every cell wave owns exactly KPT levels; no per-level guards).
+// STAMP: diagnostic instantiation with s_memtime stamps per phase (never used for timings).
+template <typename T, int KPT, bool FULL, bool STAMP>
+__global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_march_kernel(const AmtParams<T> p, const AmtMarchGrid g)
 {
     extern __shared__ __align__(16) unsigned char amt_smem[];
     const int nk = p.nk;
-    constexpr int TW = 66;                        // row buffers: 64 lanes + left/right halo
-    constexpr int N2D = 7;                        // staged 2-D rows: msftx msfty muu msfuy muv' msfvx_inv' mu_tend
+    constexpr int TW = AMT_TW, N2D = AMT_N2D;
     T *AP = reinterpret_cast<T *>(amt_smem);      // [nk][64]   dnw(k)*dvdxi(i,k)  (the terms of dmdt)
-    T *B  = AP + (size_t)nk * 64;                 // [nk][64]   ww increments
+    T *B  = AP + (size_t)nk * 64;                 // [nk][64]   ww increments, then ww(k+1) of the recurrence
     T *T1 = B + (size_t)nk * 64;                  // [2][nk][66] t_1 of row j / row j+1 (+ i halo)
     T *D2 = T1 + (size_t)2 * nk * TW;             // [2][N2D][66] 2-D inputs of row j / row j+1
-    T *S1 = D2 + (size_t)2 * N2D * TW;            // dnw | fnm | fnp | rdnw, nk entries each
+    T *DM = D2 + (size_t)2 * N2D * TW;            // [64] dmdt of the row
+    T *W0 = DM + 64;                              // [64] incoming ww(i,1,j) of the row
+    T *S1 = W0 + 64;                              // dnw | fnm | fnp | rdnw, nk entries each
     const T *s_dnw = S1, *s_fnm = S1 + nk, *s_fnp = S1 + 2 * nk, *s_rdnw = S1 + 3 * nk;
     const int t1buf = nk * TW, d2buf = N2D * TW;
 
     const int lane = threadIdx.x & 63;
     const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
     const int nwav = (int)(blockDim.x >> 6);
+    const int nc   = nwav - 1;                                           // cell waves 0..nc-1
+    const bool colw = (w == nc);                                         // the column wave
     const unsigned vo = (unsigned)lane * (unsigned)sizeof(T);            // the only per-lane offset
+
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int slot) {
+        if (STAMP) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (slot >= 0) st_acc[slot] += now - st_prev;
+            st_prev = now;
+        }
+    };
 
     // XCD-aware logical workgroup id: blocks b, b+8, b+16 ... share an XCD (round-robin
     // dispatch), so give each XCD a contiguous run of logical ids: neighbouring i-tiles
@@ -117,31 +140,14 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
     const int ja   = p.j0 + jblk * g.jrows;
     const int jb   = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
 
-    const int kf   = w * KPT;                      // my levels: zero-based kf .. kf+nlev-1
-    const int nlev = FULL ? KPT : ((nk - kf < KPT) ? (nk - kf) : KPT);
-    const bool has_above = (kf + KPT < nk);        // zero-based level kf+KPT exists
     const long idim = p.idim, js = p.jstride;
-    const T rdx = p.rdx, rdy = p.rdy, dts = p.dts;
-    const T hrdy = T(.5) * rdy, hrdx = T(.5) * rdx;
-
-    // Wave-uniform base pointers (SGPR pairs), fixed for the whole march: element
-    // (lane 0 of the tile, my first level, row ja) of every 3-D array, (lane 0, row ja) of
-    // every 2-D array.  The row advance and the level step go into 32-bit per-lane byte
-    // offsets (o3, o2), which the launcher keeps below 2^31.
-    const long e3 = (long)ja * js + (long)(p.k1 + kf) * idim + (long)tile * 64;
-    const long e2 = (long)ja * idim + (long)tile * 64;
-    const T *u_b = p.u + e3, *u1_b = p.u_1 + e3, *ft_b = p.ft + e3, *ww1_b = p.ww_1 + e3;
-    const T *vn_b = p.v + e3 + js, *v1n_b = p.v_1 + e3 + js, *t1n_b = p.t_1 + e3 + js;   // row j+1
-    T *t_b = p.t + e3, *tave_b = p.t_ave + e3, *ww_b = p.ww + e3;
-    const T *wwin_b = p.ww + (long)ja * js + (long)p.k1 * idim + (long)tile * 64;          // level 1
-    const T *mut_b = p.mut + e2;
-    T *mu_b = p.mu + e2, *mudf_b = p.mudf + e2, *muts_b = p.muts + e2, *muave_b = p.muave + e2;
     const unsigned lev = (unsigned)idim * (unsigned)sizeof(T);      // byte step of one level
     const unsigned row3 = (unsigned)js * (unsigned)sizeof(T);       // byte step of one j row (3-D)
     const unsigned row2 = lev;                                      // byte step of one j row (2-D)
+    const long e2 = (long)ja * idim + (long)tile * 64;              // (lane 0 of the tile, row ja)
 
-    // The 2-D inputs of a row are fetched ONCE per workgroup (wave q fetches array q, q+nwav, ...)
-    // one row ahead and handed to the other waves through LDS.  Slot order of D2:
+    // The 2-D inputs of a row are fetched ONCE per workgroup, one row ahead, by the column
+    // wave and handed to the cell waves through LDS.  Slot order of D2:
     //   0 msftx(j) 1 msfty(j) 2 muu(j) 3 msfuy(j) 4 muv(j+1) 5 msfvx_inv(j+1) 6 mu_tend(j)
     auto d2_src = [&](int q) -> const T * {
         switch (q) {
@@ -155,301 +161,388 @@ __global__ __launch_bounds__(KPT >= 15 ? 256 : KPT >= 8 ? 512 : 1024) void amt_m
         }
     };
 
-    // carried in registers from row to row (per owned level): the two j-face fluxes,
-    // and the prefetched inputs of the next row's P1
-    T vfm[KPT], vft[KPT];
-    T pv[KPT], pv1[KPT], pt1[KPT], pu[AMT_PF_U ? KPT : 1], pu1[AMT_PF_U ? KPT : 1];
-#pragma unroll
-    for (int m = 0; m < KPT; ++m) { vfm[m] = vft[m] = pv[m] = pv1[m] = pt1[m] = T(0); if (AMT_PF_U) pu[m] = pu1[m] = T(0); }
+    if (colw) {
+        // =====================================================================
+        // column wave
+        // =====================================================================
+        const T *wwin_b = p.ww + (long)ja * js + (long)p.k1 * idim + (long)tile * 64;   // level 1
+        const T *mut_b = p.mut + e2;
+        T *mu_b = p.mu + e2, *mudf_b = p.mudf + e2, *muts_b = p.muts + e2, *muave_b = p.muave + e2;
+        const T dts = p.dts;
 
-    // ---- prologue: j-face fluxes of row ja, t_1 row ja and the 2-D row ja into LDS buffer 0,
-    //      first prefetch ----
-    {
-        T muv_j = T(0), mvx_j = T(0);
-        if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
-        for (int q = w; q < N2D; q += nwav) {
+        // prologue: 2-D row ja into D2 buffer 0
+#pragma unroll
+        for (int q = 0; q < N2D; ++q) {
             const T *src = d2_src(q);
             if (inmem) D2[q * TW + 1 + lane] = amt_ld(src, vo);
             if (halo_r) D2[q * TW + TW - 1] = amt_ld(src + 64, vo);
         }
-#pragma unroll
-        for (int m = 0; m < KPT; ++m) {
-            if (FULL || m < nlev) {
-                const unsigned om = vo + (unsigned)m * lev;
-                const int K = kf + m;
-                if (t1ok) {
-                    const T tc = amt_ld(p.t_1 + e3, om);
-                    T1[K * TW + 1 + lane] = tc;
-                    if (act) {
-                        const T vv = amt_ld(p.v + e3, om);
-                        vfm[m] = vv + muv_j * amt_ld(p.v_1 + e3, om) * mvx_j;
-                        vft[m] = vv * (tc + amt_ld(p.t_1 + e3 - js, om));
-                        if (PF) { pv[m] = amt_ld(vn_b, om); pv1[m] = amt_ld(v1n_b, om); }
-                        if (AMT_PF_U) { pu[m] = amt_ld(u_b, om);  pu1[m] = amt_ld(u1_b, om); }
-                    }
-                    if (PF) pt1[m] = amt_ld(t1n_b, om);
-                }
-                if (edge) T1[K * TW + ehalo] = amt_ld(p.t_1 + e3 - 1, om + eoff);
-            }
-        }
-    }
-    __syncthreads();                               // S1, T1[0], D2[0] staged
+        __syncthreads();                           // S1, T1[0], D2[0] staged
 
-    unsigned o3 = vo, o2 = vo;                     // per-lane byte offsets of the current row
-    for (int jj = ja; jj <= jb; ++jj, o3 += row3, o2 += row2) {
-        T hf[KPT], tw[KPT], dv[KPT];
-        T msfty = T(1), mu_tend = T(0), tw_above = T(0);
-        const int par = (jj - ja) & 1;
-        const T *T1c = T1 + par * t1buf;                         // t_1 row j   (read)
-        T *T1n = T1 + (par ^ 1) * t1buf;                         // t_1 row j+1 (written, read next row)
-        const T *D2c = D2 + par * d2buf;                         // 2-D row j   (read)
-        T *D2n = D2 + (par ^ 1) * d2buf;                         // 2-D row j+1 (written in P2)
-        const bool more = (jj < jb);                             // another row follows in this block
-
-        // ---------------- P1: per-cell work from pure inputs ----------------
-        if (t1ok) {
+        unsigned o3 = vo, o2 = vo;
+        for (int jj = ja; jj <= jb; ++jj, o3 += row3, o2 += row2) {
+            const int par = (jj - ja) & 1;
+            const T *D2c = D2 + par * d2buf;
+            T *D2n = D2 + (par ^ 1) * d2buf;
+            const bool more = (jj < jb);
+            stamp(-1);
+            // while the cell waves do P1: fetch the next 2-D row and this row's column inputs
+            T d2v[N2D], d2h[N2D];
 #pragma unroll
-            for (int m = 0; m < KPT; ++m)
-                if (FULL || m < nlev) {
-                    if (!PF) pt1[m] = amt_ld(t1n_b, o3 + (unsigned)m * lev);
-                    T1n[(kf + m) * TW + 1 + lane] = pt1[m];                         // t_1(i,k,j+1)
-                }
-        }
-        if (edge) {
+            for (int q = 0; q < N2D; ++q) { d2v[q] = T(0); d2h[q] = T(0); }
+            if (more) {
 #pragma unroll
-            for (int m = 0; m < KPT; ++m)
-                if (FULL || m < nlev)
-                    T1n[(kf + m) * TW + ehalo] = amt_ld(t1n_b - 1, o3 + (unsigned)m * lev + eoff);
-        }
-        if (act) {
-            const T msftx = D2c[0 * TW + 1 + lane];
-            msfty = D2c[1 * TW + 1 + lane];
-            const T mm = msftx * msfty;
-            const T muu_i = D2c[2 * TW + 1 + lane], muu_ip = D2c[2 * TW + 2 + lane];
-            const T msfuy_i = D2c[3 * TW + 1 + lane], msfuy_ip = D2c[3 * TW + 2 + lane];
-            const T muv_p = D2c[4 * TW + 1 + lane], mvx_p = D2c[5 * TW + 1 + lane];
-            mu_tend = D2c[6 * TW + 1 + lane];
-            if (has_above) {
-                // wdtn at the level above my last one needs that level's t_1 pair (:227)
-                const int Ka = kf + KPT;
-                tw_above = s_fnm[Ka] * T1c[Ka * TW + 1 + lane] + s_fnp[Ka] * T1c[(Ka - 1) * TW + 1 + lane];
-            }
-#pragma unroll
-            for (int m = 0; m < KPT; ++m) {
-                if (FULL || m < nlev) {
-                    const unsigned om = o3 + (unsigned)m * lev;
-                    const int K = kf + m;
-                    const T uup = amt_ld(u_b + 1, om), u1p = amt_ld(u1_b + 1, om);   // same lines as pu/pu1
-                    const T vn = PF ? pv[m] : amt_ld(vn_b, om), v1n = PF ? pv1[m] : amt_ld(v1n_b, om), t1n = pt1[m];
-                    const T uu = AMT_PF_U ? pu[m] : amt_ld(u_b, om), u1 = AMT_PF_U ? pu1[m] : amt_ld(u1_b, om);
-                    const T t1c = T1c[K * TW + 1 + lane], t1l = T1c[K * TW + lane], t1r = T1c[K * TW + 2 + lane];
-                    // :142-146
-                    const T vfm_n = vn + muv_p * v1n * mvx_p;
-                    const T d = mm * ( rdy * (vfm_n - vfm[m])
-                                     + rdx * ( (uup + muu_ip * u1p / msfuy_ip)
-                                             - (uu  + muu_i  * u1  / msfuy_i ) ));
-                    dv[m] = d;
-                    AP[K * 64 + lane] = s_dnw[K] * d;            // the term of :147
-                    // horizontal part of :237-245
-                    const T vft_n = vn * (t1n + t1c);
-                    hf[m] = msftx * ( hrdy * (vft_n - vft[m])
-                                    + hrdx * ( uup * (t1r + t1c) - uu * (t1c + t1l) ) );
-                    // fnm(k)*t_1(k) + fnp(k)*t_1(k-1) of :227 (unused for Fortran level 1)
-                    const T t1km1 = (K > 0) ? T1c[(K > 0 ? K - 1 : 0) * TW + 1 + lane] : T(0);
-                    tw[m] = s_fnm[K] * t1c + s_fnp[K] * t1km1;
-                    vfm[m] = vfm_n; vft[m] = vft_n;              // the faces of row j+1
+                for (int q = 0; q < N2D; ++q) {
+                    const T *src = d2_src(q);
+                    if (inmem) d2v[q] = amt_ld(src, o2 + row2);
+                    if (halo_r) d2h[q] = amt_ld(src + 64, o2 + row2);
                 }
             }
-        }
-        __syncthreads();
-
-        // ---------------- P2: column integral, mass update, ww increments ----------------
-        // fetch the next row's 2-D inputs (one array per wave) and what only P3 consumes; the
-        // k chain below hides the latency
-        T d2v = T(0), d2h = T(0);
-        int d2q = -1;
-        if (more) {
-            for (int q = w; q < N2D; q += nwav) {                // at most one pass when nwav >= 7
-                if (d2q >= 0) {                                  // (rare: fewer than 7 waves) flush the previous one
-                    if (inmem) D2n[d2q * TW + 1 + lane] = d2v;
-                    if (halo_r) D2n[d2q * TW + TW - 1] = d2h;
+            T ww1in = T(0), mu_old = T(0), mut_v = T(0);
+            if (act) {
+                ww1in = amt_ld(wwin_b, o3);                      // incoming ww(i,1,j)
+                mu_old = amt_ld(mu_b, o2);
+                mut_v = amt_ld(mut_b, o2);
+            }
+            const T mu_tend = D2c[6 * TW + 1 + lane];
+            stamp(0);
+            __syncthreads();                                     // 1: AP complete
+            stamp(1);
+            T dmdt = T(0);
+            {                                                    // :147, sequential in k
+                int k = 0;
+                for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
+                    T a[AMT_CHAIN];
+#pragma unroll
+                    for (int q = 0; q < AMT_CHAIN; ++q) a[q] = AP[(k + q) * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < AMT_CHAIN; ++q) dmdt = dmdt + a[q];
                 }
-                const T *src = d2_src(q);
-                if (inmem) d2v = amt_ld(src, o2 + row2);
-                if (halo_r) d2h = amt_ld(src + 64, o2 + row2);
-                d2q = q;
+                for (; k < nk; ++k) dmdt = dmdt + AP[k * 64 + lane];
             }
-        }
-        T ww1in = T(0), mu_old = T(0), mut_v = T(0);
-        if (act) {
-            ww1in = amt_ld(wwin_b, o3);                          // incoming ww(i,1,j)
-            if (w == 0) { mu_old = amt_ld(mu_b, o2); mut_v = amt_ld(mut_b, o2); }
-        }
-        T dmdt = T(0);
-        {                                                        // :147, sequential in k
-            int k = 0;
-            for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
-                T a[AMT_CHAIN];
-#pragma unroll
-                for (int q = 0; q < AMT_CHAIN; ++q) a[q] = AP[(k + q) * 64 + lane];
-#pragma unroll
-                for (int q = 0; q < AMT_CHAIN; ++q) dmdt = dmdt + a[q];
-            }
-            for (; k < nk; ++k) dmdt = dmdt + AP[k * 64 + lane];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        T told[KPT], ftk[KPT], w1[KPT];
-        T w1_above = T(0);
-        if (act) {
-            // issue the loads that only P3 consumes: the divides below, the barrier and the ww
-            // prefix hide them (issuing them before the k chain costs 24 more live VGPRs there)
-            if (has_above) w1_above = amt_ld(ww1_b, o3 + (unsigned)KPT * lev);
-#pragma unroll
-            for (int m = 0; m < KPT; ++m) {
-                if (FULL || m < nlev) {
-                    const unsigned om = o3 + (unsigned)m * lev;
-                    told[m] = amt_ld(t_b, om);
-                    ftk[m] = amt_ld(ft_b, om);
-                    w1[m] = amt_ld(ww1_b, om);
-                }
-            }
-            // ww(i,1,j) is overwritten by wave 0 after the next barrier: make sure this wave's
-            // copy has arrived before it gets there
-            asm volatile("" : "+v"(ww1in));
-            if (w == 0) {                                        // :151-157
+            DM[lane] = dmdt;
+            W0[lane] = ww1in;
+            stamp(2);
+            __syncthreads();                                     // 2: DM, W0 published
+            stamp(3);
+            if (act) {                                           // :151-157
                 const T mu_new = mu_old + dts * (dmdt + mu_tend);
                 amt_st(mu_b, o2, mu_new);
                 amt_st(mudf_b, o2, (dmdt + mu_tend));
                 amt_st(muts_b, o2, mut_v + mu_new);
                 amt_st(muave_b, o2, T(.5) * ((T(1.) + p.epssm) * mu_new + (T(1.) - p.epssm) * mu_old));
             }
+            if (more) {                                          // hand the 2-D row j+1 over
 #pragma unroll
-            for (int m = 0; m < KPT; ++m) {
-                if (FULL || m < nlev) {
-                    const int K = kf + m;
-                    B[K * 64 + lane] = s_dnw[K] * (dmdt + dv[m] + mu_tend) / msfty;   // :161
+                for (int q = 0; q < N2D; ++q) {
+                    if (inmem) D2n[q * TW + 1 + lane] = d2v[q];
+                    if (halo_r) D2n[q * TW + TW - 1] = d2h[q];
                 }
             }
-        }
-        if (d2q >= 0) {                                          // hand the 2-D row j+1 to everybody
-            if (inmem) D2n[d2q * TW + 1 + lane] = d2v;
-            if (halo_r) D2n[d2q * TW + TW - 1] = d2h;
-        }
-        __syncthreads();
-
-        // ---------------- P3: ww prefix, vertical flux, theta ----------------
-        // prefetch the inputs of the next row's P1 under the prefix chain and the stores
-        if (PF && more) {
-#pragma unroll
-            for (int m = 0; m < KPT; ++m) {
-                if (FULL || m < nlev) {
-                    const unsigned om = o3 + row3 + (unsigned)m * lev;
-                    if (act) {
-                        pv[m] = amt_ld(vn_b, om); pv1[m] = amt_ld(v1n_b, om);
-                        if (AMT_PF_U) { pu[m] = amt_ld(u_b, om);  pu1[m] = amt_ld(u1_b, om); }
-                    }
-                    if (t1ok) pt1[m] = amt_ld(t1n_b, om);
-                }
-            }
-        }
-        if (act) {
-            T wwu = ww1in;                                       // ww(i,1,j) of the recurrence
-            {                                                    // :161, sequential in k
+            stamp(4);
+            __syncthreads();                                     // 3: B (increments) complete
+            stamp(5);
+            {                                                    // :161, sequential in k; B[k] <- ww(k+1)
+                T wwu = ww1in;
                 int k = 0;
-                for (; k + AMT_CHAIN <= kf; k += AMT_CHAIN) {
+                for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
                     T b[AMT_CHAIN];
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) b[q] = B[(k + q) * 64 + lane];
 #pragma unroll
-                    for (int q = 0; q < AMT_CHAIN; ++q) wwu = wwu - b[q];
+                    for (int q = 0; q < AMT_CHAIN; ++q) { wwu = wwu - b[q]; B[(k + q) * 64 + lane] = wwu; }
                 }
-                for (; k < kf; ++k) wwu = wwu - B[k * 64 + lane];
+                for (; k < nk; ++k) { wwu = wwu - B[k * 64 + lane]; B[k * 64 + lane] = wwu; }
             }
-            T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];   // wdtn(i,1) = 0 (:220)
+            stamp(6);
+            __syncthreads();                                     // 4: ww of the recurrence published
+            stamp(7);
+        }
+    } else {
+        // =====================================================================
+        // cell waves
+        // =====================================================================
+        const int kf   = w * KPT;                      // my levels: zero-based kf .. kf+nlev-1
+        const int nlev = FULL ? KPT : ((nk - kf < KPT) ? (nk - kf) : KPT);
+        const bool has_above = (kf + KPT < nk);        // zero-based level kf+KPT exists
+        const T rdx = p.rdx, rdy = p.rdy, dts = p.dts;
+        const T hrdy = T(.5) * rdy, hrdx = T(.5) * rdx;
+
+        // Wave-uniform base pointers (SGPR pairs), fixed for the whole march: element
+        // (lane 0 of the tile, my first level, row ja) of every 3-D array.  The row advance and
+        // the level step go into a 32-bit per-lane byte offset (o3), which the launcher keeps
+        // below 2^31.
+        const long e3 = (long)ja * js + (long)(p.k1 + kf) * idim + (long)tile * 64;
+        const T *u_b = p.u + e3, *u1_b = p.u_1 + e3, *ft_b = p.ft + e3, *ww1_b = p.ww_1 + e3;
+        const T *vn_b = p.v + e3 + js, *v1n_b = p.v_1 + e3 + js, *t1n_b = p.t_1 + e3 + js;   // row j+1
+        T *t_b = p.t + e3, *tave_b = p.t_ave + e3, *ww_b = p.ww + e3;
+
+        // carried in registers from row to row (per owned level): the two j-face fluxes
+        T vfm[KPT], vft[KPT];
+#pragma unroll
+        for (int m = 0; m < KPT; ++m) { vfm[m] = vft[m] = T(0); }
+
+        // ---- prologue: j-face fluxes of row ja, t_1 row ja into LDS buffer 0 ----
+        {
+            T muv_j = T(0), mvx_j = T(0);
+            if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
                 if (FULL || m < nlev) {
-                    const unsigned om = o3 + (unsigned)m * lev;
+                    const unsigned om = vo + (unsigned)m * lev;
                     const int K = kf + m;
-                    const T wout = wwu - w1[m];                  // :170
-                    amt_st(ww_b, om, wout);
-                    // wdtn at level K+1 (:221,:227)
-                    T wd_n = T(0);
-                    const T wwu_n = wwu - B[K * 64 + lane];
-                    if (m + 1 < KPT) {
-                        if (FULL || m + 1 < nlev) wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
-                    } else if (has_above) {
-                        wd_n = (wwu_n - w1_above) * tw_above;
+                    if (t1ok) {
+                        const T tc = amt_ld(p.t_1 + e3, om);
+                        T1[K * TW + 1 + lane] = tc;
+                        if (act) {
+                            const T vv = amt_ld(p.v + e3, om);
+                            vfm[m] = vv + muv_j * amt_ld(p.v_1 + e3, om) * mvx_j;
+                            vft[m] = vv * (tc + amt_ld(p.t_1 + e3 - js, om));
+                        }
                     }
-                    amt_st(tave_b, om, told[m]);                                          // :211
-                    const T tb = told[m] + msfty * dts * ftk[m];                          // :212
-                    amt_st(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));   // :237-246
-                    wwu = wwu_n; wd_k = wd_n;
+                    if (edge) T1[K * TW + ehalo] = amt_ld(p.t_1 + e3 - 1, om + eoff);
                 }
             }
         }
-        // no barrier needed here: AP and the T1/D2 buffers written next are touched only after
-        // every wave has passed this row's second barrier, B after the first barrier of the next row
+        __syncthreads();                               // S1, T1[0], D2[0] staged
+
+        unsigned o3 = vo;                              // per-lane byte offset of the current row
+        for (int jj = ja; jj <= jb; ++jj, o3 += row3) {
+            T hf[KPT], tw[KPT], dv[KPT];
+            T msfty = T(1), mu_tend = T(0), tw_above = T(0);
+            const int par = (jj - ja) & 1;
+            const T *T1c = T1 + par * t1buf;                         // t_1 row j   (read)
+            T *T1n = T1 + (par ^ 1) * t1buf;                         // t_1 row j+1 (written, read next row)
+            const T *D2c = D2 + par * d2buf;                         // 2-D row j   (read)
+            stamp(-1);
+
+            // ---------------- P1: per-cell work from pure inputs ----------------
+            if (t1ok && !act) {                                      // the (at most two) columns beside the window
+#pragma unroll
+                for (int m = 0; m < KPT; ++m)
+                    if (FULL || m < nlev)
+                        T1n[(kf + m) * TW + 1 + lane] = amt_ld(t1n_b, o3 + (unsigned)m * lev);
+            }
+            if (edge) {
+#pragma unroll
+                for (int m = 0; m < KPT; ++m)
+                    if (FULL || m < nlev)
+                        T1n[(kf + m) * TW + ehalo] = amt_ld(t1n_b - 1, o3 + (unsigned)m * lev + eoff);
+            }
+            if (act) {
+                const T msftx = D2c[0 * TW + 1 + lane];
+                msfty = D2c[1 * TW + 1 + lane];
+                const T mm = msftx * msfty;
+                const T muu_i = D2c[2 * TW + 1 + lane], muu_ip = D2c[2 * TW + 2 + lane];
+                const T msfuy_i = D2c[3 * TW + 1 + lane], msfuy_ip = D2c[3 * TW + 2 + lane];
+                const T muv_p = D2c[4 * TW + 1 + lane], mvx_p = D2c[5 * TW + 1 + lane];
+                mu_tend = D2c[6 * TW + 1 + lane];
+                if (has_above) {
+                    // wdtn at the level above my last one needs that level's t_1 pair (:227)
+                    const int Ka = kf + KPT;
+                    tw_above = s_fnm[Ka] * T1c[Ka * TW + 1 + lane] + s_fnp[Ka] * T1c[(Ka - 1) * TW + 1 + lane];
+                }
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    if (FULL || m < nlev) {
+                        const unsigned om = o3 + (unsigned)m * lev;
+                        const int K = kf + m;
+                        const T vn = amt_ld(vn_b, om), v1n = amt_ld(v1n_b, om);
+                        const T t1n = amt_ld(t1n_b, om);                       // t_1(i,k,j+1)
+                        T1n[K * TW + 1 + lane] = t1n;
+                        const T uu = amt_ld(u_b, om), uup = amt_ld(u_b + 1, om);
+                        const T u1 = amt_ld(u1_b, om), u1p = amt_ld(u1_b + 1, om);
+                        const T t1c = T1c[K * TW + 1 + lane], t1l = T1c[K * TW + lane], t1r = T1c[K * TW + 2 + lane];
+                        // :142-146
+                        const T vfm_n = vn + muv_p * v1n * mvx_p;
+                        const T d = mm * ( rdy * (vfm_n - vfm[m])
+                                         + rdx * ( (uup + muu_ip * u1p / msfuy_ip)
+                                                 - (uu  + muu_i  * u1  / msfuy_i ) ));
+                        dv[m] = d;
+                        AP[K * 64 + lane] = s_dnw[K] * d;            // the term of :147
+                        // horizontal part of :237-245
+                        const T vft_n = vn * (t1n + t1c);
+                        hf[m] = msftx * ( hrdy * (vft_n - vft[m])
+                                        + hrdx * ( uup * (t1r + t1c) - uu * (t1c + t1l) ) );
+                        // fnm(k)*t_1(k) + fnp(k)*t_1(k-1) of :227 (unused for Fortran level 1)
+                        const T t1km1 = (K > 0) ? T1c[(K > 0 ? K - 1 : 0) * TW + 1 + lane] : T(0);
+                        tw[m] = s_fnm[K] * t1c + s_fnp[K] * t1km1;
+                        vfm[m] = vfm_n; vft[m] = vft_n;              // the faces of row j+1
+                    }
+                }
+            }
+            stamp(0);
+            __syncthreads();                                         // 1: AP complete
+            stamp(1);
+
+            // while the column wave sums dmdt: issue the loads that only P3 consumes
+            T told[KPT], ftk[KPT], w1[KPT];
+            T w1_above = T(0);
+            if (act) {
+                if (has_above) w1_above = amt_ld(ww1_b, o3 + (unsigned)KPT * lev);
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    if (FULL || m < nlev) {
+                        const unsigned om = o3 + (unsigned)m * lev;
+                        told[m] = amt_ld(t_b, om);
+                        ftk[m] = amt_ld(ft_b, om);
+                        w1[m] = amt_ld(ww1_b, om);
+                    }
+                }
+            }
+            stamp(2);
+            __syncthreads();                                         // 2: DM, W0 published
+            stamp(3);
+            if (act) {
+                const T dmdt = DM[lane];
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    if (FULL || m < nlev) {
+                        const int K = kf + m;
+                        B[K * 64 + lane] = s_dnw[K] * (dmdt + dv[m] + mu_tend) / msfty;   // :161
+                    }
+                }
+            }
+            stamp(4);
+            __syncthreads();                                         // 3: B (increments) complete
+            stamp(5);
+            // nothing to do while the column wave runs the ww recurrence
+            stamp(6);
+            __syncthreads();                                         // 4: B[k] = ww(k+1) of the recurrence
+            stamp(7);
+
+            // ---------------- P3: vertical flux, theta ----------------
+            if (act) {
+                T wwu = (kf == 0) ? W0[lane] : B[(kf > 0 ? kf - 1 : 0) * 64 + lane];   // ww of :161 at my first level
+                T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];   // wdtn(i,1) = 0 (:220)
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    if (FULL || m < nlev) {
+                        const unsigned om = o3 + (unsigned)m * lev;
+                        const int K = kf + m;
+                        const T wout = wwu - w1[m];                  // :170
+                        amt_st(ww_b, om, wout);
+                        // wdtn at level K+1 (:221,:227)
+                        T wd_n = T(0);
+                        const T wwu_n = B[K * 64 + lane];
+                        if (m + 1 < KPT) {
+                            if (FULL || m + 1 < nlev) wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
+                        } else if (has_above) {
+                            wd_n = (wwu_n - w1_above) * tw_above;
+                        }
+                        amt_st(tave_b, om, told[m]);                                          // :211
+                        const T tb = told[m] + msfty * dts * ftk[m];                          // :212
+                        amt_st(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));   // :237-246
+                        wwu = wwu_n; wd_k = wd_n;
+                    }
+                }
+            }
+            // No barrier here.  What the next row's P1 writes (AP, and the T1 buffer that was
+            // READ in this row's P1) is read by nobody after barrier 1 of this row; B and W0
+            // (read above) are next written after barrier 2 / barrier 1 of the next row.
+        }
+    }
+    if (STAMP && g.stamps && lane == 0) {
+        for (int q = 0; q < 8; ++q) g.stamps[((size_t)blockIdx.x * 16 + w) * 8 + q] = st_acc[q];
     }
 }
 
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
-// Levels per wave.  Workgroup size is bounded by the kernel's __launch_bounds__: 16 waves
-// (KPT < 8), 8 waves (KPT 8..10), 4 waves (KPT 15).  Smallest KPT that fits wins (most waves to
-// hide latency, fewest registers per lane); a KPT that divides nk is preferred (no level guards).
+
+// Levels per cell wave.  Workgroup size (cell waves + the column wave) is bounded by the
+// kernel's __launch_bounds__: 16 waves (KPT < 8), 11 waves (KPT 8..10), 5 waves (KPT 15).
+// Smallest KPT that fits wins (most waves to hide latency, fewest registers per lane); a KPT
+// that divides nk is preferred (no level guards).
 template <typename T> static int amt_march_kpt(int nk)
 {
     static const int cand[] = {2, 4, 5, 6, 8, 10, 15};
-    auto maxw = [](int k) { return k >= 15 ? 4 : k >= 8 ? 8 : 16; };
+    auto maxc = [](int k) { return k >= 15 ? 4 : k >= 8 ? 10 : 15; };  // cell waves
     const int forced = amt_env_int("AMT_MARCH_KPT", 0);
     for (int k : cand)
-        if (k == forced && (nk + k - 1) / k <= maxw(k)) return k;
+        if (k == forced && (nk + k - 1) / k <= maxc(k)) return k;
     int first_fit = 0;
     for (int k : cand) {
-        if ((nk + k - 1) / k > maxw(k)) continue;
+        if ((nk + k - 1) / k > maxc(k)) continue;
         if (!first_fit) first_fit = k;
-        if (nk % k == 0 && k <= 2 * first_fit) return k;
+        // fp64 keeps ~9 values per level live: beyond KPT 4 it spills, so take the first fit
+        if (nk % k == 0 && k <= 2 * first_fit && (sizeof(T) == 4 || k <= 4)) return k;
     }
     return first_fit;
 }
 
-template <typename T> static size_t amt_march_lds(int nk) { return ((size_t)2 * nk * 64 + (size_t)2 * nk * 66 + 2 * 7 * 66 + 4 * (size_t)nk) * sizeof(T); }
+template <typename T> static size_t amt_march_lds(int nk)
+{
+    return ((size_t)2 * nk * 64 + (size_t)2 * nk * AMT_TW + 2 * AMT_N2D * AMT_TW + 128 + 4 * (size_t)nk) * sizeof(T);
+}
+
+template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
+{
+    // the per-lane byte offsets of the march are 32-bit
+    const long row_bytes = p.jstride * (long)sizeof(T);
+    return ((1L << 31) - 16L * p.idim * (long)sizeof(T)) / row_bytes - 3;
+}
 
 template <typename T> bool amt_march_supported(const AmtParams<T> &p)
 {
-    const long row_bytes = p.jstride * (long)sizeof(T);
-    const long max_rows = ((1L << 31) - 16L * p.idim * (long)sizeof(T)) / row_bytes - 3;
-    return p.nk >= 1 && amt_march_kpt<T>(p.nk) != 0 && amt_march_lds<T>(p.nk) <= 160 * 1024 - 1024 && max_rows >= 1;
+    return p.nk >= 1 && amt_march_kpt<T>(p.nk) != 0 && amt_march_lds<T>(p.nk) <= 160 * 1024
+           && amt_march_max_rows(p) >= 1;
 }
 
-template <typename T, int KPT, bool FULL, bool PF>
+template <typename T, int KPT, bool FULL>
 static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, size_t lds)
 {
-    const int nw = (p.nk + KPT - 1) / KPT;
+    const int nw = (p.nk + KPT - 1) / KPT + 1;       // cell waves + the column wave
     if (lds > 64 * 1024) {
         static thread_local size_t granted = 0;      // per kernel instantiation
         if (lds > granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_kernel<T, KPT, FULL, PF>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_kernel<T, KPT, FULL, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             granted = lds;
         }
     }
-    hipLaunchKernelGGL((amt_march_kernel<T, KPT, FULL, PF>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
+    if (KPT == 4 && FULL && sizeof(T) == 8 && amt_env_int("AMT_MARCH_STAMP", 0)) {
+        // diagnostic instantiation: per-phase cycle sums of every wave, printed to stderr
+        // (its fences forbid overlaps the real kernel has: read shares, never quote its run time)
+        AmtMarchGrid gs = g;
+        const size_t n = (size_t)g.nwg * 16 * 8;
+        if (hipMalloc((void **)&gs.stamps, n * 8) != hipSuccess) return hipGetLastError();
+        (void)hipMemsetAsync(gs.stamps, 0, n * 8, stream);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_kernel<T, 4, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((amt_march_kernel<T, 4, true, true>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, gs);
+        (void)hipStreamSynchronize(stream);
+        unsigned long long *h = (unsigned long long *)malloc(n * 8);
+        (void)hipMemcpy(h, gs.stamps, n * 8, hipMemcpyDeviceToHost);
+        double cell[8] = {0}, col[8] = {0}, w0[8] = {0};
+        for (size_t b = 0; b < (size_t)g.nwg; ++b)
+            for (int ww = 0; ww < nw; ++ww)
+                for (int q = 0; q < 8; ++q) {
+                    const double x = (double)h[(b * 16 + ww) * 8 + q];
+                    if (ww == nw - 1) col[q] += x; else cell[q] += x;
+                    if (ww == 0) w0[q] += x;
+                }
+        const char *names[8] = {"P1", "bar1", "P2a", "bar2", "P2b", "bar3", "idle", "bar4+P3"};
+        const double rows = (double)g.nwg * g.jrows;
+        fprintf(stderr, "[amt stamps] cycles per row: phase cell-mean / wave0 / column-wave\n[amt stamps]");
+        for (int q = 0; q < 8; ++q)
+            fprintf(stderr, "  %s %.0f/%.0f/%.0f", names[q], cell[q] / (rows * (nw - 1)), w0[q] / rows, col[q] / rows);
+        fprintf(stderr, "\n");
+        free(h);
+        (void)hipFree(gs.stamps);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((amt_march_kernel<T, KPT, FULL, false>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
     return hipGetLastError();
 }
 
 template <typename T, int KPT>
 static hipError_t amt_march_launch_kpt(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, size_t lds)
 {
-    // prefetching costs 3*KPT live values: worth it where registers allow (fp32), not in fp64 at KPT 4
-    static const int pf = amt_env_int("AMT_MARCH_PF", sizeof(T) == 4 ? 1 : 0);
-    if (p.nk % KPT == 0)
-        return pf ? amt_march_launch_full<T, KPT, true, true>(stream, p, g, lds)
-                  : amt_march_launch_full<T, KPT, true, false>(stream, p, g, lds);
-    return amt_march_launch_full<T, KPT, false, false>(stream, p, g, lds);
+    return (p.nk % KPT == 0) ? amt_march_launch_full<T, KPT, true>(stream, p, g, lds)
+                             : amt_march_launch_full<T, KPT, false>(stream, p, g, lds);
 }
 
 template <typename T>
@@ -460,6 +553,7 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
     const int kpt = amt_march_kpt<T>(p.nk);
     if (kpt == 0) return hipErrorNotSupported;
     AmtMarchGrid g;
+    g.stamps = nullptr;
     g.tile_lo = p.i0 / 64;
     g.ntile_i = p.i1 / 64 - g.tile_lo + 1;
     // rows per workgroup: 32 amortises the per-block prologue (4 extra array-rows) to 1.6 % of
@@ -470,9 +564,7 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
         jrows = want < 4 ? 4 : want > 32 ? 32 : (int)want;
     }
     if (jrows > nj) jrows = nj;
-    // the per-lane byte offsets of the march are 32-bit
-    const long row_bytes = p.jstride * (long)sizeof(T);
-    const long max_rows = ((1L << 31) - 16L * p.idim * (long)sizeof(T)) / row_bytes - 3;
+    const long max_rows = amt_march_max_rows(p);
     if (max_rows < 1) return hipErrorNotSupported;
     if (jrows > max_rows) jrows = (int)max_rows;
     g.jrows = jrows;
