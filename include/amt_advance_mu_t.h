@@ -105,6 +105,14 @@ int amt_advance_mu_t_f64(
     int ims, int ime, int jms, int jme, int kms, int kme,
     int its, int ite, int jts, int jte, int kts, int kte);
 
+/* Page-lock / release a host array (hipHostRegister).  When all ten 3-D arrays of a one-shot
+ * call are page-locked (by these, or allocated pinned by the caller as the reference driver
+ * does, advance_mu_t_driver.cu:97-167) the call streams the window in j chunks over two HIP
+ * streams so that H2D, kernel and D2H overlap; with pageable arrays it copies synchronously
+ * in one piece like the reference wrapper.  Pin once, outside the time loop. */
+int amt_host_pin(void *ptr, size_t bytes);
+int amt_host_unpin(void *ptr);
+
 /* ------------------------------------------------------------------------
  * (2) Device-resident drop-ins: the same call with every array pointer in
  *     DEVICE memory of the current device, enqueued on `hip_stream`

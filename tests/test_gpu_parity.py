@@ -80,6 +80,61 @@ def test_one_shot_host_call_matches_oracle(pkg, oracle, shape, flag, dtype):
     assert_patch_equal(pkg, p, want, f"one-shot {shape}/{flag}")
 
 
+@pytest.mark.parametrize("rows", [1, 5, 13])
+def test_streamed_one_shot_chunks_match_oracle(pkg, oracle, monkeypatch, rows):
+    """The one-shot drop-in streams the window in j chunks over two HIP streams
+    (H2D -> kernel -> D2H per chunk); any chunking must give the oracle's bits."""
+    monkeypatch.setenv("AMT_STREAM_ROWS", str(rows))
+    for flag in ("none", "specified"):
+        p = cases.make_case(pkg, "64x40x64", flag, np.float64)
+        want = p.copy()
+        oracle.advance_mu_t(*want.args())
+        pkg.advance_mu_t(*p.args())
+        assert_patch_equal(pkg, p, want, f"streamed one-shot rows={rows} {flag}")
+
+
+def test_streamed_one_shot_with_pinned_host_arrays(pkg, oracle):
+    """amt_host_pin on the ten 3-D arrays switches the one-shot call to the chunked two-stream
+    pipeline (default chunk size); results must not change."""
+    import ctypes
+    from wrf_model_cuda_sample_amd import lib
+    L = pkg.load_library()
+    S = pkg.synth
+    p = S.make_patch(S.domain_bounds(700, 60, 150), pkg.GridConfig(nested=True), seed=8)   # ~43 MB per 3-D array
+    want = p.copy()
+    oracle.advance_mu_t_omp(*want.args(), nthreads=8)
+    pinned = []
+    try:
+        for n in S.RANK3:
+            a = p.arrays[n]
+            lib.check(L.amt_host_pin(a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+            pinned.append(a)
+        pkg.advance_mu_t(*p.args())
+    finally:
+        for a in pinned:
+            lib.check(L.amt_host_unpin(a.ctypes.data_as(ctypes.c_void_p)))
+    assert_patch_equal(pkg, p, want, "pinned streamed one-shot")
+
+
+def test_fp32_run_against_fp64_oracle_at_stated_tolerance(pkg, oracle, torch_mod):
+    """BASELINE.json configs[4]: an fp32 run judged against the fp64 Fortran.  Tolerance, stated:
+    per output array, max |fp32 - fp64| <= 2e-5 * max |fp64| (a few fp32 ulps of the field scale,
+    accumulated over the NK-level chains); element-wise relative error is meaningless here because
+    ww and t pass through zero."""
+    S = pkg.synth
+    b = S.domain_bounds(256, 80, 96, aligned=True)
+    dev = S.make_patch(b, pkg.GridConfig(specified=True), dtype=np.float32, seed=31, device="cuda:0")
+    want = S.make_patch(b, pkg.GridConfig(specified=True), dtype=np.float64, seed=31)
+    pkg.advance_mu_t(*dev.args())
+    torch_mod.cuda.synchronize()
+    oracle.advance_mu_t_omp(*want.args(), nthreads=8)
+    got = dev.to_host()
+    for n in S.OUTPUTS:
+        w = want.arrays[n]
+        err = np.abs(got.arrays[n].astype(np.float64) - w).max()
+        assert err <= 2e-5 * np.abs(w).max(), (n, err, np.abs(w).max())
+
+
 def test_against_committed_golden_vectors(pkg, torch_mod):
     """HIP path straight against tests/golden (outputs of the reference Fortran itself)."""
     from pathlib import Path

@@ -210,6 +210,41 @@ struct StreamGuard {
 };
 }  // namespace
 
+// Streamed one-shot: the window's j rows are cut into chunks; chunk c runs
+//   H2D (its rows + one halo row each side of the five arrays the stencil reads across
+//   rows) -> kernel -> D2H (its rows of the seven outputs)
+// on stream c % 2 with its own set of device buffers, so the transfers of one chunk overlap
+// the kernel and the opposite-direction transfer of the other.  That only pays when the host
+// arrays are page-locked (amt_host_pin / hipHostRegister / hipHostMalloc by the caller, once,
+// like the reference driver's cudaHostAlloc, advance_mu_t_driver.cu:97-167): copies from
+// pageable memory are staged synchronously, and pinning inside the call costs more than it
+// saves (measured: 61 vs 41 ms at 512x60x512 fp64).  So: pinned 3-D arrays -> chunked pipeline;
+// pageable -> one chunk (the reference's own synchronous scheme, advance_mu_t_no_async.cu:
+// 245-306,366-390).  Chunks are legal because a row's outputs depend on other rows' INPUTS only.
+static bool amt_is_pinned(const void *ptr)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+extern "C" int amt_host_pin(void *ptr, size_t bytes)
+{
+    if (!ptr) return amt_fail(AMT_ERR_INVALID_ARG, "null pointer");
+    AMT_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return AMT_OK;
+}
+
+extern "C" int amt_host_unpin(void *ptr)
+{
+    if (!ptr) return amt_fail(AMT_ERR_INVALID_ARG, "null pointer");
+    AMT_HIP(hipHostUnregister(ptr));
+    return AMT_OK;
+}
+
 template <typename T>
 static int amt_host_call(const AmtArgs<T> &h)
 {
@@ -222,67 +257,104 @@ static int amt_host_call(const AmtArgs<T> &h)
     AMT_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return amt_fail(AMT_ERR_NO_DEVICE, "no HIP device visible");
 
-    // Device patch = the j rows the window touches plus one halo row each side
-    // (the stencil reads j-1 and j+1 of pure inputs only); all i, all k.
-    const int ja = w.j_start - 1, jb = w.j_end + 1;
     const long idim = p.idim, kdim = p.kdim;
-    const long nrow = jb - ja + 1;
-    const size_t n3 = (size_t)idim * kdim * nrow, n2 = (size_t)idim * nrow, n1 = (size_t)kdim;
-    const size_t off3 = (size_t)(ja - h.jms) * idim * kdim, off2 = (size_t)(ja - h.jms) * idim;
+    const size_t r3 = (size_t)idim * kdim, r2 = (size_t)idim, n1 = (size_t)kdim;   // elements per j row
+    const int nj = w.j_end - w.j_start + 1;
+    // chunking (pinned host arrays only): ~320 MB of 3-D input per chunk (measured best at 1024x60x1024 fp64)
+    const char *env_rows = getenv("AMT_STREAM_ROWS");    // test/tuning knob: rows per chunk
+    const bool pinned = amt_is_pinned(h.ww) && amt_is_pinned(h.ww_1) && amt_is_pinned(h.u) && amt_is_pinned(h.u_1)
+                        && amt_is_pinned(h.v) && amt_is_pinned(h.v_1) && amt_is_pinned(h.t) && amt_is_pinned(h.t_1)
+                        && amt_is_pinned(h.t_ave) && amt_is_pinned(h.ft);
+    long rows = env_rows ? atol(env_rows) : pinned ? (long)((320u << 20) / (r3 * sizeof(T) * 10) + 1) : (long)nj;
+    if (rows < 1) rows = 1;
+    if (rows > nj) rows = nj;
+    const int nchunk = (int)((nj + rows - 1) / rows);
+    const int nset = nchunk > 1 ? 2 : 1;
+    const size_t crow = (size_t)rows + 2;                     // device rows per buffer set
+
+    // every array, OUT ones included (contents outside the window and level kte must survive,
+    // cf. advance_mu_t_no_async.cu:259,270-272)
+    struct Item { const T *host; int rank; bool halo; bool out; };
+    const Item items[26] = {
+        {h.ww, 3, false, true}, {h.ww_1, 3, false, false}, {h.u, 3, false, false}, {h.u_1, 3, false, false},
+        {h.v, 3, true, false}, {h.v_1, 3, true, false}, {h.mu, 2, false, true}, {h.mut, 2, false, false},
+        {h.muave, 2, false, true}, {h.muts, 2, false, true}, {h.muu, 2, false, false}, {h.muv, 2, true, false},
+        {h.mudf, 2, false, true}, {h.t, 3, false, true}, {h.t_1, 3, true, false}, {h.t_ave, 3, false, true},
+        {h.ft, 3, false, false}, {h.mu_tend, 2, false, false}, {h.dnw, 1, false, false}, {h.fnm, 1, false, false},
+        {h.fnp, 1, false, false}, {h.rdnw, 1, false, false}, {h.msfuy, 2, false, false},
+        {h.msfvx_inv, 2, true, false}, {h.msftx, 2, false, false}, {h.msfty, 2, false, false},
+    };
 
     DeviceArena arena;
-    arena.size = (10 * (n3 * sizeof(T) + 256)) + (12 * (n2 * sizeof(T) + 256)) + 4 * (n1 * sizeof(T) + 256);
+    arena.size = (size_t)nset * (10 * (r3 * crow * sizeof(T) + 256) + 12 * (r2 * crow * sizeof(T) + 256))
+                 + 4 * (n1 * sizeof(T) + 256);
     if (hipMalloc((void **)&arena.base, arena.size) != hipSuccess) {
         (void)hipGetLastError();
         arena.base = nullptr;
         return amt_fail(AMT_ERR_ALLOC, "hipMalloc of %zu bytes failed", arena.size);
     }
-    StreamGuard sg;
-    AMT_HIP(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
-
-    AmtArgs<T> d = h;
-    d.jms = ja; d.jme = jb;
-    // every array, OUT ones included (contents outside the window must survive,
-    // cf. advance_mu_t_no_async.cu:259,270-272)
-    struct Item { const T *host; const T **dev_c; T **dev_m; int rank; };
-    T *dww, *dmu, *dmuave, *dmuts, *dmudf, *dt, *dtave;
-    Item items[] = {
-        {h.ww, nullptr, &dww, 3}, {h.ww_1, &d.ww_1, nullptr, 3}, {h.u, &d.u, nullptr, 3},
-        {h.u_1, &d.u_1, nullptr, 3}, {h.v, &d.v, nullptr, 3}, {h.v_1, &d.v_1, nullptr, 3},
-        {h.mu, nullptr, &dmu, 2}, {h.mut, &d.mut, nullptr, 2}, {h.muave, nullptr, &dmuave, 2},
-        {h.muts, nullptr, &dmuts, 2}, {h.muu, &d.muu, nullptr, 2}, {h.muv, &d.muv, nullptr, 2},
-        {h.mudf, nullptr, &dmudf, 2}, {h.t, nullptr, &dt, 3}, {h.t_1, &d.t_1, nullptr, 3},
-        {h.t_ave, nullptr, &dtave, 3}, {h.ft, &d.ft, nullptr, 3}, {h.mu_tend, &d.mu_tend, nullptr, 2},
-        {h.dnw, &d.dnw, nullptr, 1}, {h.fnm, &d.fnm, nullptr, 1}, {h.fnp, &d.fnp, nullptr, 1},
-        {h.rdnw, &d.rdnw, nullptr, 1}, {h.msfuy, &d.msfuy, nullptr, 2},
-        {h.msfvx_inv, &d.msfvx_inv, nullptr, 2}, {h.msftx, &d.msftx, nullptr, 2},
-        {h.msfty, &d.msfty, nullptr, 2},
-    };
-    for (Item &it : items) {
-        const size_t n = it.rank == 3 ? n3 : it.rank == 2 ? n2 : n1;
-        const size_t off = it.rank == 3 ? off3 : it.rank == 2 ? off2 : 0;
-        T *dev = static_cast<T *>(arena.take(n * sizeof(T)));
-        AMT_HIP(hipMemcpyAsync(dev, it.host + off, n * sizeof(T), hipMemcpyHostToDevice, sg.s));
-        if (it.dev_c) *it.dev_c = dev; else *it.dev_m = dev;
+    T *dev[2][26];
+    for (int f = 0; f < 26; ++f) {
+        if (items[f].rank == 1) {
+            dev[0][f] = dev[1][f] = static_cast<T *>(arena.take(n1 * sizeof(T)));
+        } else {
+            const size_t n = (items[f].rank == 3 ? r3 : r2) * crow;
+            for (int s = 0; s < nset; ++s) dev[s][f] = static_cast<T *>(arena.take(n * sizeof(T)));
+            if (nset == 1) dev[1][f] = dev[0][f];
+        }
     }
-    d.ww = dww; d.mu = dmu; d.muave = dmuave; d.muts = dmuts; d.mudf = dmudf; d.t = dt; d.t_ave = dtave;
+    StreamGuard sg[2];
+    for (int s = 0; s < nset; ++s) AMT_HIP(hipStreamCreateWithFlags(&sg[s].s, hipStreamNonBlocking));
 
-    rc = amt_device_call<T>(sg.s, AMT_VARIANT_AUTO, d);
-    if (rc != AMT_OK) { (void)hipStreamSynchronize(sg.s); return rc; }
-
-    // outputs: rows j_start..j_end only (row 1 .. nrow-2 of the device patch)
-    const size_t o3 = (size_t)idim * kdim, o2 = (size_t)idim;
-    const size_t m3 = (size_t)idim * kdim * (nrow - 2), m2 = (size_t)idim * (nrow - 2);
-    struct Out { T *host; T *dev; int rank; };
-    Out outs[] = {{h.ww, dww, 3}, {h.t, dt, 3}, {h.t_ave, dtave, 3}, {h.mu, dmu, 2},
-                  {h.muave, dmuave, 2}, {h.muts, dmuts, 2}, {h.mudf, dmudf, 2}};
-    for (Out &o : outs) {
-        const size_t skip = o.rank == 3 ? o3 : o2, n = o.rank == 3 ? m3 : m2;
-        const size_t off = (o.rank == 3 ? off3 : off2) + skip;
-        AMT_HIP(hipMemcpyAsync(o.host + off, o.dev + skip, n * sizeof(T), hipMemcpyDeviceToHost, sg.s));
+    for (int f = 0; f < 26; ++f)                              // the four 1-D arrays, once
+        if (items[f].rank == 1)
+            AMT_HIP(hipMemcpyAsync(dev[0][f], items[f].host, n1 * sizeof(T), hipMemcpyHostToDevice, sg[0].s));
+    if (nset == 2) {
+        hipEvent_t ev;
+        AMT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        AMT_HIP(hipEventRecord(ev, sg[0].s));
+        AMT_HIP(hipStreamWaitEvent(sg[1].s, ev, 0));
+        AMT_HIP(hipEventDestroy(ev));
     }
-    AMT_HIP(hipStreamSynchronize(sg.s));
-    return AMT_OK;
+
+    for (int c = 0; c < nchunk; ++c) {
+        const int s = c % nset;
+        hipStream_t st = sg[s].s;
+        const int c0 = w.j_start + (int)(c * rows);
+        const int c1 = (c0 + rows - 1 < w.j_end) ? (int)(c0 + rows - 1) : w.j_end;
+        const int ja = c0 - 1;                                // device row 0 <-> Fortran row ja
+        for (int f = 0; f < 26; ++f) {
+            const Item &it = items[f];
+            if (it.rank == 1) continue;
+            const size_t row = it.rank == 3 ? r3 : r2;
+            const int lo = it.halo ? c0 - 1 : c0, hi = it.halo ? c1 + 1 : c1;
+            AMT_HIP(hipMemcpyAsync(dev[s][f] + (size_t)(lo - ja) * row, it.host + (size_t)(lo - h.jms) * row,
+                                   (size_t)(hi - lo + 1) * row * sizeof(T), hipMemcpyHostToDevice, st));
+        }
+        AmtArgs<T> d = h;
+        T **q = dev[s];
+        d.ww = q[0]; d.ww_1 = q[1]; d.u = q[2]; d.u_1 = q[3]; d.v = q[4]; d.v_1 = q[5]; d.mu = q[6];
+        d.mut = q[7]; d.muave = q[8]; d.muts = q[9]; d.muu = q[10]; d.muv = q[11]; d.mudf = q[12];
+        d.t = q[13]; d.t_1 = q[14]; d.t_ave = q[15]; d.ft = q[16]; d.mu_tend = q[17];
+        d.dnw = q[18]; d.fnm = q[19]; d.fnp = q[20]; d.rdnw = q[21]; d.msfuy = q[22];
+        d.msfvx_inv = q[23]; d.msftx = q[24]; d.msfty = q[25];
+        d.jms = ja; d.jme = c1 + 1; d.jts = c0; d.jte = c1;  // a tile of the same domain (global jds, jde)
+        rc = amt_device_call<T>(st, AMT_VARIANT_AUTO, d);
+        if (rc != AMT_OK) break;
+        for (int f = 0; f < 26; ++f) {
+            const Item &it = items[f];
+            if (!it.out) continue;
+            const size_t row = it.rank == 3 ? r3 : r2;
+            AMT_HIP(hipMemcpyAsync(const_cast<T *>(it.host) + (size_t)(c0 - h.jms) * row, dev[s][f] + row,
+                                   (size_t)(c1 - c0 + 1) * row * sizeof(T), hipMemcpyDeviceToHost, st));
+        }
+    }
+    for (int s = 0; s < nset; ++s) {
+        hipError_t e = hipStreamSynchronize(sg[s].s);
+        if (e != hipSuccess && rc == AMT_OK)
+            rc = amt_fail(AMT_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    }
+    return rc;
 }
 
 #define AMT_PACK_ARGS(T)                                                                        \

@@ -43,6 +43,19 @@ MODULE amt_c_binding
          integer(c_int) :: rc
       end function
 
+      ! page-lock / release a host array so that the one-shot call streams it
+      function amt_host_pin(ptr, bytes) bind(C, name="amt_host_pin") result(rc)
+         import :: c_ptr, c_size_t, c_int
+         type(c_ptr), value :: ptr
+         integer(c_size_t), value :: bytes
+         integer(c_int) :: rc
+      end function
+      function amt_host_unpin(ptr) bind(C, name="amt_host_unpin") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: ptr
+         integer(c_int) :: rc
+      end function
+
       ! error text of the calling thread (NUL-terminated C string)
       function amt_last_error() bind(C, name="amt_last_error") result(msg)
          import :: c_ptr

@@ -64,6 +64,8 @@ SYMBOLS = {
     "amt_synth_fill_host": (_I, [_I, _I, _P, ctypes.c_uint64] + [_L] * 9),
     "amt_synth_fill_device": (_I, [_P, _I, _I, _P, ctypes.c_uint64] + [_L] * 9),
     "amt_calib_stream_copy": (_I, [_P, _P, _P, ctypes.c_size_t, _I]),
+    "amt_host_pin": (_I, [_P, ctypes.c_size_t]),
+    "amt_host_unpin": (_I, [_P]),
 }
 
 
