@@ -1,0 +1,75 @@
+"""The reference drivers' on-disk format (big-endian 4-byte per-variable streams) and the replay
+tool that mirrors their flow: read a dump directory, CALL advance_mu_t, print the comparison
+report against the golden '*_output.bin' files."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import bits_equal
+
+ROOT = Path(__file__).resolve().parent.parent
+TOOLS = ROOT / "wrf-model-cuda-sample_amd" / "tools"
+
+
+@pytest.fixture(scope="module")
+def replay(pkg):
+    r = subprocess.run(["make", "-C", str(TOOLS), "all"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return TOOLS / "advance_mu_t_replay"
+
+
+def test_dump_directory_round_trip(pkg, tmp_path):
+    p = cases.make_case(pkg, "37x5x11_ragged", "specified_periodic_x", np.float32)
+    pkg.wrfdump.write_inputs(tmp_path, p)
+    # the reference's file set: 17 bounds + kds, 4 scalars, 3 flags, 23 arrays
+    assert len(list(tmp_path.iterdir())) == 18 + 4 + 3 + 23
+    assert (tmp_path / "grid_u_save.bin").stat().st_size == p.arrays["u_1"].size * 4
+    raw = np.fromfile(tmp_path / "ide.bin", dtype=np.uint8)
+    assert list(raw) == [0, 0, 0, 38]                       # big-endian int 38
+    q = pkg.wrfdump.read_inputs(tmp_path)
+    assert q.bounds == p.bounds and q.config == p.config
+    assert (q.rdx, q.dts) == (np.float32(p.rdx), np.float32(p.dts))
+    for n in pkg.wrfdump.INPUT_FILES:
+        assert bits_equal(q.arrays[n], p.arrays[n]), n
+
+
+def test_replay_fails_loudly_without_a_device(pkg, replay, tmp_path):
+    if pkg.load_library().amt_device_count() > 0:
+        pytest.skip("a device is present")
+    pkg.wrfdump.write_inputs(tmp_path, cases.make_case(pkg, "16x8x16", "none", np.float32))
+    r = subprocess.run([str(replay), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "advance_mu_t failed" in r.stderr
+    r = subprocess.run([str(replay)], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,flag", [("64x40x64", "none"), ("64x40x64", "specified"), ("130x3x7_tile", "nested")])
+def test_replay_matches_golden_directory(pkg, oracle, replay, tmp_path, shape, flag):
+    p = cases.make_case(pkg, shape, flag, np.float32)
+    ind, gold, out = tmp_path / "in", tmp_path / "gold", tmp_path / "out"
+    out.mkdir()
+    pkg.wrfdump.write_inputs(ind, p)
+    want = p.copy()
+    for n in ("muave", "muts", "mudf"):                     # INTENT(OUT): the replay starts them at zero
+        want.arrays[n][...] = 0
+    oracle.advance_mu_t(*want.args())
+    pkg.wrfdump.write_outputs(gold, want)
+    r = subprocess.run([str(replay), str(ind), str(gold), "--write", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all 8 arrays bit-equal" in r.stdout
+    assert r.stdout.count("max ulp = 0") == 8
+    got = pkg.wrfdump.read_outputs(out, p.bounds)
+    for n in pkg.wrfdump.OUTPUT_FILES:
+        assert bits_equal(got[n], want.arrays[n]), n
+    # one flipped bit in a golden file must be reported: 1 non-equal value, 1 ulp
+    bad = want.arrays["t"].copy()
+    j, k, i = bad.shape[0] // 2, 0, bad.shape[2] // 2
+    bad[j, k, i] = np.nextafter(bad[j, k, i], np.float32(np.inf))
+    bad.astype(">f4").tofile(gold / "grid_t_2_output.bin")
+    r = subprocess.run([str(replay), str(ind), str(gold)], capture_output=True, text=True)
+    assert r.returncode == 3
+    assert "# of non-equal values: 1" in r.stdout and "max ulp = 1" in r.stdout

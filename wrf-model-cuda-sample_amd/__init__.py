@@ -8,6 +8,7 @@ Host-side mirror of the reference's interface for this one path:
   the C-ABI of ``include/amt_advance_mu_t.h`` into the hand-written gfx950 kernels.
 * ``GridConfig``         -- the three ``grid_config_rec_type`` logicals the routine reads.
 * ``synth``              -- seeded WRF-shaped synthetic inputs (host and device fill).
+* ``wrfdump``            -- the reference drivers' big-endian per-variable dump format.
 * ``patch``              -- resident device patch (torch-allocated arrays) and j-slab
   decomposition with the one-row input-halo exchange over torch.distributed (RCCL).
 
@@ -21,3 +22,4 @@ from .lib import AmtError, load_library, library_path  # noqa: F401
 from .api import advance_mu_t, compute_window, VARIANT_AUTO, VARIANT_COLUMN, VARIANT_MARCH  # noqa: F401
 from . import synth  # noqa: F401
 from . import patch  # noqa: F401
+from . import wrfdump  # noqa: F401
