@@ -249,6 +249,53 @@ def test_slab_stepper_single_rank_on_gpu(pkg, torch_mod):
     assert_patch_equal(pkg, dev.to_host(), ref.to_host(), "stepper world=1")
 
 
+@pytest.mark.parametrize("world,overlap", [(2, True), (3, True), (4, False)])
+def test_slab_steppers_on_one_gpu_reproduce_the_unsplit_domain(pkg, torch_mod, world, overlap):
+    """The N > 1 sweep logic on a real GPU: `world` slabs of one domain, each with its own
+    SlabStepper (comm stream, interior launch overlapped with the exchange, edge rows after it),
+    all in this process; the RCCL send/recv is replaced by device-to-device copies of the same
+    rows.  Halo rows start as NaN, so only a correct exchange + ordering gives the unsplit result."""
+    import torch
+    S = pkg.synth
+    dims = (200, 20, 61)
+    g = S.domain_bounds(*dims, aligned=True)
+    cfg = pkg.GridConfig(specified=True)
+    whole = S.make_patch(g, cfg, seed=5, device="cuda:0")
+    slabs = []
+    for r in range(world):
+        sb = S.slab_bounds(g, r, world)
+        pt = S.make_patch(sb, cfg, seed=5, global_dims=dims, device="cuda:0")
+        for name in S.HALO_FROM_ABOVE:
+            if r < world - 1:
+                pt.arrays[name][-1].fill_(float("nan"))
+        if r > 0:
+            pt.arrays["t_1"][0].fill_(float("nan"))
+        slabs.append(pt)
+
+    def transport(st):
+        a = st.patch.arrays
+        if st.above is not None:
+            up = slabs[st.above].arrays
+            for name in S.HALO_FROM_ABOVE:
+                a[name][-1].copy_(up[name][1], non_blocking=True)
+        if st.below is not None:
+            a["t_1"][0].copy_(slabs[st.below].arrays["t_1"][-2], non_blocking=True)
+
+    steppers = [pkg.patch.SlabStepper(slabs[r], r, world, pkg.advance_mu_t, overlap=overlap, transport=transport)
+                for r in range(world)]
+    for _ in range(3):
+        pkg.advance_mu_t(*whole.args())
+        for st in steppers:
+            st.step()
+    torch.cuda.synchronize()
+    ref = whole.to_host()
+    for r in range(world):
+        b = slabs[r].bounds
+        got = slabs[r].to_host()
+        for n in S.OUTPUTS:
+            assert bits_equal(got.arrays[n][1:-1], ref.arrays[n][b.jts - g.jms: b.jte - g.jms + 1]), (r, n)
+
+
 def test_full_size_slab_properties(pkg, oracle, torch_mod):
     """BASELINE.json configs[2] shape in i and k (4096 x 60) on as many rows as fit quickly:
     the oracle recomputes randomly placed 3-row j-slabs from regenerated inputs."""
