@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=64, help="j rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="gloo: bring-up mode -- halo rows staged through the host, ranks may share a GPU "
+                         "(RCCL refuses that); never a performance number")
     return ap.parse_args()
 
 
@@ -118,11 +121,16 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    if a.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = g.load_package()
     S = pkg.synth
@@ -142,7 +150,7 @@ def main():
         if rank > 0:
             dev.arrays["t_1"][0].fill_(float("nan"))
     stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap,
-                                    variant=a.variant)
+                                    variant=a.variant, stage_through_host=(a.backend == "gloo"))
     torch.cuda.synchronize()
 
     verified, why = None, ""
@@ -175,7 +183,8 @@ def main():
     ev_ms = ev0.elapsed_time(ev1)
 
     if world > 1:
-        t = torch.tensor([wall, ev_ms, 1.0 if verified in (None, True) else 0.0], device=device, dtype=torch.float64)
+        rdev = device if a.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([wall, ev_ms, 1.0 if verified in (None, True) else 0.0], device=rdev, dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tmin = t.clone()
@@ -217,6 +226,7 @@ def main():
                                    f"{world} j-slab(s), one-row RCCL halo exchange per sweep",
                        "ni": a.ni, "nk": a.nk, "nj": a.nj, "variant": a.variant,
                        "halo_overlap": (not a.no_overlap) if world > 1 else None,
+                       "halo_transport": ("rccl" if a.backend == "nccl" else "gloo-host-staged (bring-up)") if world > 1 else None,
                        "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -135,6 +135,28 @@ def test_fp32_run_against_fp64_oracle_at_stated_tolerance(pkg, oracle, torch_mod
         assert err <= 2e-5 * np.abs(w).max(), (n, err, np.abs(w).max())
 
 
+def test_empty_and_degenerate_windows(pkg, oracle, torch_mod):
+    """Windows with no column (specified on a 2-cell-wide domain), one column, one row: the call
+    succeeds, matches the oracle and leaves everything else untouched."""
+    S = pkg.synth
+    for dims, flags in (((2, 3, 2), dict(specified=True)),        # i_start=2 > i_end=1: nothing to do
+                        ((3, 2, 5), dict(nested=True)),           # exactly one column in i
+                        ((9, 4, 3), dict(specified=True)),        # exactly one row in j
+                        ((1, 1, 1), dict())):                     # a single cell
+        b = S.domain_bounds(*dims)
+        host = S.make_patch(b, pkg.GridConfig(**flags), seed=2)
+        want = host.copy()
+        oracle.advance_mu_t(*want.args())
+        for variant in variants(pkg):
+            dev = host.to_device("cuda:0")
+            pkg.advance_mu_t(*dev.args(), variant=variant)
+            torch_mod.cuda.synchronize()
+            assert_patch_equal(pkg, dev.to_host(), want, f"degenerate {dims} {flags} variant{variant}")
+        one = host.copy()
+        pkg.advance_mu_t(*one.args())
+        assert_patch_equal(pkg, one, want, f"degenerate one-shot {dims} {flags}")
+
+
 def test_against_committed_golden_vectors(pkg, torch_mod):
     """HIP path straight against tests/golden (outputs of the reference Fortran itself)."""
     from pathlib import Path

@@ -36,6 +36,48 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
+def bind_device_call(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
+                     t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,
+                     msfuy, msfvx_inv, msftx, msfty, config_flags,
+                     ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme,
+                     its, ite, jts, jte, kts, kte, *, stream=None, variant=VARIANT_AUTO):
+    """Validate once and return a zero-argument callable that enqueues this device-resident
+    advance_mu_t call (same tensors, same bounds) -- for per-sub-step loops, where rebuilding the
+    48 ctypes arguments every sweep would make the host the bottleneck."""
+    import torch
+    L = _lib.load_library()
+    arrays = (ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1, t_ave, ft, mu_tend,
+              dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty)
+    dt = ww.dtype
+    if dt not in (torch.float32, torch.float64):
+        raise TypeError(f"unsupported dtype {dt}")
+    for a in arrays:
+        if not (_is_torch(a) and a.is_cuda and a.dtype == dt and a.is_contiguous()):
+            raise TypeError("device call needs contiguous CUDA tensors of one dtype")
+    real = ctypes.c_float if dt == torch.float32 else ctypes.c_double
+    fn = L.amt_advance_mu_t_device_f32 if dt == torch.float32 else L.amt_advance_mu_t_device_f64
+    if stream is None:
+        stream = torch.cuda.current_stream(ww.device)
+    handle = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+    cargs = ([ctypes.c_void_p(handle), int(variant)]
+             + [ctypes.c_void_p(a.data_ptr()) for a in arrays[:18]]
+             + [real(float(x)) for x in (rdx, rdy, dts, epssm)]
+             + [ctypes.c_void_p(a.data_ptr()) for a in arrays[18:]]
+             + list(flags_as_ints(config_flags))
+             + [int(x) for x in (ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte)])
+    device_index = ww.device.index if ww.device.index is not None else torch.cuda.current_device()
+    keep = arrays                                   # keeps the tensors alive as long as the closure
+
+    def call():
+        if torch.cuda.current_device() != device_index:
+            torch.cuda.set_device(device_index)
+        status = fn(*cargs)
+        if status:
+            _lib.check(status)
+        return keep is None
+    return call
+
+
 def advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
                  t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,
                  msfuy, msfvx_inv, msftx, msfty, config_flags,
@@ -85,3 +127,6 @@ def advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf,
                 *[real(float(s)) for s in (rdx, rdy, dts, epssm)],
                 *[a.ctypes.data_as(ctypes.c_void_p) for a in arrays_b], *flags, *ints)
     _lib.check(status)
+
+
+advance_mu_t.bind = bind_device_call        # SlabStepper pre-marshals its per-sweep launches through this

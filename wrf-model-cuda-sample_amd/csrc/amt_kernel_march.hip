@@ -45,6 +45,12 @@ static int amt_env_int(const char *name, int dflt)
     return (s && *s) ? atoi(s) : dflt;
 }
 
+#ifndef AMT_NT_STORE
+#define AMT_NT_STORE 0
+#endif
+#ifndef AMT_COL_PRIO
+#define AMT_COL_PRIO 0
+#endif
 #ifndef AMT_CHAIN
 #define AMT_CHAIN 10    /* LDS reads kept in flight by the sequential k chains */
 #endif
@@ -70,6 +76,16 @@ template <typename T>
 __device__ __forceinline__ void amt_st(T *ubase, unsigned voff, T x)
 {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(ubase) + voff) = x;
+}
+// streaming store: the three 3-D outputs are written once and not read again in the sweep
+template <typename T>
+__device__ __forceinline__ void amt_st_stream(T *ubase, unsigned voff, T x)
+{
+#if AMT_NT_STORE
+    __builtin_nontemporal_store(x, reinterpret_cast<T *>(reinterpret_cast<char *>(ubase) + voff));
+#else
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(ubase) + voff) = x;
+#endif
 }
 
 constexpr int AMT_TW = 66;    // LDS row buffers: 64 lanes + left/right halo
@@ -169,6 +185,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
         const T *mut_b = p.mut + e2;
         T *mu_b = p.mu + e2, *mudf_b = p.mudf + e2, *muts_b = p.muts + e2, *muave_b = p.muave + e2;
         const T dts = p.dts;
+        if (AMT_COL_PRIO) __builtin_amdgcn_s_setprio(3);   // the other 15 waves wait on this one's chains
 
         // prologue: 2-D row ja into D2 buffer 0
 #pragma unroll
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                         const unsigned om = o3 + (unsigned)m * lev;
                         const int K = kf + m;
                         const T wout = wwu - w1[m];                  // :170
-                        amt_st(ww_b, om, wout);
+                        amt_st_stream(ww_b, om, wout);
                         // wdtn at level K+1 (:221,:227)
                         T wd_n = T(0);
                         const T wwu_n = B[K * 64 + lane];
@@ -430,9 +447,9 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                         } else if (has_above) {
                             wd_n = (wwu_n - w1_above) * tw_above;
                         }
-                        amt_st(tave_b, om, told[m]);                                          // :211
+                        amt_st_stream(tave_b, om, told[m]);                                          // :211
                         const T tb = told[m] + msfty * dts * ftk[m];                          // :212
-                        amt_st(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));   // :237-246
+                        amt_st_stream(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));   // :237-246
                         wwu = wwu_n; wd_k = wd_n;
                     }
                 }

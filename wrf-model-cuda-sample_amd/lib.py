@@ -23,7 +23,10 @@ class AmtError(RuntimeError):
 
 
 def library_path() -> Path:
-    return PKG_DIR / _LIB_NAME
+    """The in-tree HIP library; AMT_LIBRARY overrides it (A/B builds of the kernels)."""
+    import os
+    override = os.environ.get("AMT_LIBRARY")
+    return Path(override) if override else PKG_DIR / _LIB_NAME
 
 
 _lib = None

@@ -40,12 +40,18 @@ class SlabStepper:
     """
 
     def __init__(self, patch: Patch, rank: int, world: int, compute: Callable, *,
-                 group=None, overlap: bool = True, variant: int = 0, transport: Optional[Callable] = None):
+                 group=None, overlap: bool = True, variant: int = 0, transport: Optional[Callable] = None,
+                 stage_through_host: bool = False):
         self.patch, self.rank, self.world = patch, rank, world
         self.compute, self.group, self.overlap, self.variant = compute, group, overlap, variant
         # transport(stepper): replaces the torch.distributed exchange (tests run several slabs of
         # one domain in ONE process on one GPU and copy the halo rows device-to-device)
         self.transport = transport
+        self._bound = {}          # (jts, jte) -> pre-marshalled device call (see api.bind_device_call)
+        # stage_through_host: the process group cannot move device memory (gloo): bounce every row
+        # through a host buffer.  Debug/bring-up only -- lets the whole N > 1 bench path run with
+        # several ranks sharing one GPU, which RCCL refuses.
+        self.stage_through_host = stage_through_host
         self.below: Optional[int] = rank - 1 if rank > 0 else None
         self.above: Optional[int] = rank + 1 if rank < world - 1 else None
         any_arr = patch.arrays["t_1"]
@@ -88,6 +94,21 @@ class SlabStepper:
         ops = self._p2p_ops()
         if not ops:
             return
+        if self.stage_through_host and self.on_gpu:
+            dist = _dist()
+            staged, recvs = [], []
+            for op in ops:
+                if op.op is dist.isend:
+                    staged.append(dist.P2POp(dist.isend, op.tensor.cpu(), op.peer, op.group, op.tag))
+                else:
+                    host = op.tensor.new_empty(op.tensor.shape, device="cpu")
+                    recvs.append((op.tensor, host))
+                    staged.append(dist.P2POp(dist.irecv, host, op.peer, op.group, op.tag))
+            for req in dist.batch_isend_irecv(staged):
+                req.wait()
+            for dev, host in recvs:
+                dev.copy_(host, non_blocking=False)
+            return
         for req in _dist().batch_isend_irecv(ops):
             req.wait()
 
@@ -105,11 +126,18 @@ class SlabStepper:
     def _tile(self, jts: int, jte: int, stream):
         if jte < jts:
             return
-        args = self.patch.with_bounds(jts=jts, jte=jte).args()
         if self.on_gpu:
-            self.compute(*args, stream=stream, variant=self.variant)
+            call = self._bound.get((jts, jte))
+            if call is None:
+                args = self.patch.with_bounds(jts=jts, jte=jte).args()
+                binder = getattr(self.compute, "bind", None)
+                if binder is None:                   # a plain callable: marshal on every call
+                    self.compute(*args, stream=stream, variant=self.variant)
+                    return
+                call = self._bound[(jts, jte)] = binder(*args, stream=stream, variant=self.variant)
+            call()
         else:
-            self.compute(*args)
+            self.compute(*self.patch.with_bounds(jts=jts, jte=jte).args())
 
     def step(self):
         b = self.patch.bounds
