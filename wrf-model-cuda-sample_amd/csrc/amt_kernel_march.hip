@@ -573,12 +573,34 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
     g.stamps = nullptr;
     g.tile_lo = p.i0 / 64;
     g.ntile_i = p.i1 / 64 - g.tile_lo + 1;
-    // rows per workgroup: 32 amortises the per-block prologue (4 extra array-rows) to 1.6 % of
-    // the reads; small domains use shorter blocks so that at least ~512 workgroups exist
+    // Rows per workgroup.  A block costs its rows plus a prologue (4 extra array-rows of loads,
+    // about half a row of time); workgroups run in rounds of `slots` = CUs x resident
+    // workgroups per CU, so the sweep takes about  rounds(r) * (r + 0.5)  row-times.  Pick the r
+    // that minimises it: for the whole 4096-row domain any r near 32 is within 1 %, but for a
+    // 510-row j-slab (8 GPUs) r = 32 would leave the last round 6 % full (1040 workgroups on 256
+    // CUs) and cost 17 % more than r = 11.  Small launches get short blocks (more workgroups).
     int jrows = amt_env_int("AMT_MARCH_JROWS", 0);
     if (jrows < 1) {
-        const long want = ((long)nj * g.ntile_i) / 512;
-        jrows = want < 4 ? 4 : want > 32 ? 32 : (int)want;
+        static int slots = 0;
+        if (slots == 0) {
+            int dev = 0, cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            (void)hipGetLastError();
+            slots = cus;
+        }
+        const size_t lds_need = amt_march_lds<T>(p.nk);
+        const int per_cu = (int)((160u * 1024u) / (lds_need ? lds_need : 1));     // LDS is what bounds residency
+        const long sl = (long)slots * (per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu);
+        double best = 1e300;
+        for (int r = 4; r <= 64 && r <= nj; ++r) {
+            const long blocks = (long)g.ntile_i * ((nj + r - 1) / r);
+            const long rounds = (blocks + sl - 1) / sl;
+            const double cost = (double)rounds * (r + 0.5);
+            if (cost < best - 1e-9 || (cost < best + 1e-9 && r > jrows)) { best = cost; jrows = r; }
+        }
+        if (jrows < 1) jrows = nj;                                // nj < 4
     }
     if (jrows > nj) jrows = nj;
     const long max_rows = amt_march_max_rows(p);
