@@ -100,10 +100,35 @@ def cpu_baseline(pkg, oracle, dims, dtype, seed, rows, seconds):
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     cells = ni * nk * rows
-    return {"value": round(cells / med / 1e6, 2), "unit": "Mcells/s", "cores": threads, "kind": "port",
-            "sample": f"{ni}x{nk}x{rows} j-slab of the same synthetic domain, median of {len(times)} sweeps, "
-                      f"gcc -O2 OpenMP j-tiles ({threads} threads)",
-            "ms_per_sweep_sample": round(med * 1e3, 3)}
+    out = {"value": round(cells / med / 1e6, 2), "unit": "Mcells/s", "cores": threads, "kind": "port",
+           "sample": f"{ni}x{nk}x{rows} j-slab of the same synthetic domain, median of {len(times)} sweeps, "
+                     f"gcc -O2 OpenMP j-tiles ({threads} threads)",
+           "ms_per_sweep_sample": round(med * 1e3, 3)}
+    # single thread (the reference's own configuration: OpenMP commented out,
+    # advance_mu_t_driver.f90:175-209) on a shorter slab
+    r1 = max(1, min(8, rows))
+    s1 = gb.replace(jms=jlo - 1, jme=jlo + r1, jts=jlo, jte=jlo + r1 - 1)
+    p1 = S.make_patch(s1, pkg.GridConfig(), dtype=dtype, seed=seed, global_dims=dims)
+    oracle.advance_mu_t(*p1.args())
+    t1 = []
+    t_end = time.perf_counter() + min(3.0, seconds)
+    while len(t1) < 3 or (time.perf_counter() < t_end and len(t1) < 50):
+        t0 = time.perf_counter()
+        oracle.advance_mu_t(*p1.args())
+        t1.append(time.perf_counter() - t0)
+    out["one_thread_Mcells_s"] = round(ni * nk * r1 / float(np.median(t1)) / 1e6, 2)
+    # the reference Fortran itself (oracle/_ref, built from the reference's sources where they lie;
+    # its five debug dumps per call go to /dev/null), one thread, same short slab
+    if oracle.have_ref(np.dtype(dtype).itemsize):
+        p2 = S.make_patch(s1, pkg.GridConfig(), dtype=dtype, seed=seed, global_dims=dims)
+        oracle.ref_advance_mu_t(*p2.args())
+        t2 = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle.ref_advance_mu_t(*p2.args())
+            t2.append(time.perf_counter() - t0)
+        out["reference_fortran_one_thread_Mcells_s"] = round(ni * nk * r1 / float(np.median(t2)) / 1e6, 2)
+    return out
 
 
 def main():
