@@ -177,6 +177,19 @@ def main():
     stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap,
                                     variant=a.variant, stage_through_host=(a.backend == "gloo"))
     torch.cuda.synchronize()
+    if world > 1:
+        # establish the RCCL point-to-point connections outside any timed or verified step (the
+        # first send/recv between two ranks builds their communicator, which takes seconds);
+        # the inputs are static, so an extra exchange changes nothing
+        stepper.exchange_halos()
+        torch.cuda.synchronize()
+        if rank < world - 1:                       # re-poison: the verification must see the in-step exchange
+            for name in S.HALO_FROM_ABOVE:
+                dev.arrays[name][-1].fill_(float("nan"))
+        if rank > 0:
+            dev.arrays["t_1"][0].fill_(float("nan"))
+        torch.cuda.synchronize()
+        dist.barrier()
 
     verified, why = None, ""
     oracle = None
