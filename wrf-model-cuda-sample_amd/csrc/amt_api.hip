@@ -481,6 +481,19 @@ extern "C" int amt_synth_fill_device(void *hip_stream, int field, int dtype_byte
 // ---------------------------------------------------------------------------
 // (3) resident domain handle
 // ---------------------------------------------------------------------------
+namespace {
+// makes the domain's device current for the duration of a call and restores the caller's
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int want)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = (hipSetDevice(want) == hipSuccess);
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
 struct amt_domain {
     int dtype_bytes = 8;
     int periodic_x = 0, specified = 0, nested = 0;
@@ -502,6 +515,7 @@ struct amt_domain {
 extern "C" int amt_domain_destroy(amt_domain *d)
 {
     if (!d) return AMT_OK;
+    DeviceScope scope(d->device);
     for (void *&q : d->field)
         if (q) { (void)hipFree(q); q = nullptr; }
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -565,6 +579,7 @@ extern "C" int amt_domain_set_variant(amt_domain *d, int variant)
 extern "C" int amt_domain_upload(amt_domain *d, int field, const void *host)
 {
     if (!d || !host || field < 0 || field >= AMT_F_COUNT) return amt_fail(AMT_ERR_INVALID_ARG, "bad upload argument");
+    DeviceScope scope(d->device);
     AMT_HIP(hipMemcpyAsync(d->field[field], host, d->count(field) * d->dtype_bytes, hipMemcpyHostToDevice, d->stream));
     AMT_HIP(hipStreamSynchronize(d->stream));
     return AMT_OK;
@@ -573,6 +588,7 @@ extern "C" int amt_domain_upload(amt_domain *d, int field, const void *host)
 extern "C" int amt_domain_download(amt_domain *d, int field, void *host)
 {
     if (!d || !host || field < 0 || field >= AMT_F_COUNT) return amt_fail(AMT_ERR_INVALID_ARG, "bad download argument");
+    DeviceScope scope(d->device);
     AMT_HIP(hipMemcpyAsync(host, d->field[field], d->count(field) * d->dtype_bytes, hipMemcpyDeviceToHost, d->stream));
     AMT_HIP(hipStreamSynchronize(d->stream));
     return AMT_OK;
@@ -583,6 +599,7 @@ extern "C" int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,
                                          long gidim, long gkdim, long gjdim)
 {
     if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    DeviceScope scope(d->device);
     const long idim = d->ime - d->ims + 1, kdim = d->kme - d->kms + 1, jdim = d->jme - d->jms + 1;
     for (int f = 0; f < AMT_F_COUNT; ++f) {
         int rc = amt_synth_fill_device(d->stream, f, d->dtype_bytes, d->field[f], seed,
@@ -620,12 +637,14 @@ static int amt_domain_step_t(amt_domain *d, int n_sweeps)
 extern "C" int amt_domain_step(amt_domain *d, int n_sweeps)
 {
     if (!d || n_sweeps < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad step argument");
+    DeviceScope scope(d->device);
     return d->dtype_bytes == 8 ? amt_domain_step_t<double>(d, n_sweeps) : amt_domain_step_t<float>(d, n_sweeps);
 }
 
 extern "C" int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_total)
 {
     if (!d || n_sweeps < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad step argument");
+    DeviceScope scope(d->device);
     AMT_HIP(hipEventRecord(d->ev0, d->stream));
     int rc = amt_domain_step(d, n_sweeps);
     if (rc) return rc;
@@ -640,6 +659,7 @@ extern "C" int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_tota
 extern "C" int amt_domain_sync(amt_domain *d)
 {
     if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    DeviceScope scope(d->device);
     AMT_HIP(hipStreamSynchronize(d->stream));
     return AMT_OK;
 }

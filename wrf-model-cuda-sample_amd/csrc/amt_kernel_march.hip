@@ -512,12 +512,16 @@ static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &
 {
     const int nw = (p.nk + KPT - 1) / KPT + 1;       // cell waves + the column wave
     if (lds > 64 * 1024) {
-        static thread_local size_t granted = 0;      // per kernel instantiation
-        if (lds > granted) {
+        // the attribute is per device and per kernel instantiation; remember what was granted
+        static thread_local size_t granted[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+        if (lds > granted[slot] || slot != dev) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_kernel<T, KPT, FULL, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            granted = lds;
+            granted[slot] = lds;
         }
     }
     if (KPT == 4 && FULL && sizeof(T) == 8 && amt_env_int("AMT_MARCH_STAMP", 0)) {
