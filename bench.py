@@ -49,6 +49,11 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=64, help="j rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single-GPU projection: do the per-sweep work of ONE rank of an N-slab run (interior + "
+                         "edge launches, second stream, halo rows copied device-to-device from local buffers); "
+                         "prints a projection line, never the benchmark metric")
+    ap.add_argument("--emulate-rank", type=int, default=-1)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: bring-up mode -- halo rows staged through the host, ranks may share a GPU "
                          "(RCCL refuses that); never a performance number")
@@ -131,8 +136,57 @@ def cpu_baseline(pkg, oracle, dims, dtype, seed, rows, seconds):
     return out
 
 
+def emulate_one_rank(a):
+    """Per-GPU time of an N-slab run, measured on one GPU: the slab of one rank, the same three
+    launches and two streams per sweep, the halo rows arriving by device-to-device copies instead
+    of RCCL.  Projection only (no xGMI, no neighbour skew)."""
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    S = pkg.synth
+    world = a.emulate_world
+    rank = a.emulate_rank if a.emulate_rank >= 0 else world // 2
+    torch.cuda.set_device(0)
+    dtype = np.float64 if a.dtype == "f64" else np.float32
+    dims = (a.ni, a.nk, a.nj)
+    gb = S.domain_bounds(*dims, aligned=True)
+    sb = S.slab_bounds(gb, rank, world)
+    dev = S.make_patch(sb, pkg.GridConfig(), dtype=dtype, seed=a.seed, global_dims=dims, device="cuda:0")
+    src = {n: dev.arrays[n][-1].clone() for n in S.HALO_FROM_ABOVE}
+    src_below = dev.arrays["t_1"][0].clone()
+
+    def transport(st):
+        if st.above is not None:
+            for n in S.HALO_FROM_ABOVE:
+                st.patch.arrays[n][-1].copy_(src[n], non_blocking=True)
+        if st.below is not None:
+            st.patch.arrays["t_1"][0].copy_(src_below, non_blocking=True)
+
+    st = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap,
+                               variant=a.variant, transport=transport)
+    for _ in range(max(a.warmup, 1)):
+        st.step()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        st.step()
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = wall * 1e3 / a.steps
+    cells = a.ni * a.nk * a.nj
+    print(json.dumps({"projection": f"one rank of {world} (rank {rank}, rows {sb.jts}..{sb.jte}) on one GPU",
+                      "ms_per_step": round(ms, 4), "event_ms_per_step": round(ev0.elapsed_time(ev1) / a.steps, 4),
+                      "projected_Mcells_s_all_ranks": round(cells / (ms * 1e-3) / 1e6, 1),
+                      "note": "halo rows by device-to-device copy; no xGMI transfer, no neighbour skew"}), flush=True)
+
+
 def main():
     a = parse()
+    if a.emulate_world > 1:
+        return emulate_one_rank(a)
     import torch
     import torch.distributed as dist
     import __graft_entry__ as g
