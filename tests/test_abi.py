@@ -30,6 +30,17 @@ def test_every_declared_symbol_is_exported(pkg):
         assert hasattr(L, name), f"{name} declared in include/amt_advance_mu_t.h but not exported"
 
 
+def test_headers_are_plain_c99(tmp_path):
+    """include/*.h must be consumable by the reference's C host code (gcc -std=c99)."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "amt_advance_mu_t.h"\n#include "amt_synth.h"\n'
+                   'int main(void) { return amt_field_rank(AMT_F_T) == 3 && AMT_OK == 0 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", str(ROOT / "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_version_and_status_strings(pkg):
     L = pkg.load_library()
     assert b"gfx950" in L.amt_version()
