@@ -35,6 +35,7 @@
 // :217-250 (theta); the fusion of the three Fortran phases is legal because a
 // column never reads another column's outputs.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include "amt_params.h"
@@ -465,6 +466,353 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
 }
 
 // ---------------------------------------------------------------------------
+// AMT_VARIANT_MARCH, LDS-DMA flavour (the fast path when the arrays allow it)
+// ---------------------------------------------------------------------------
+// Same mapping, same four barriers, same arithmetic as amt_march_kernel.  Difference: the rows
+// j+2 of t_1 and v that the NEXT row's P1 needs are fetched by LDS-DMA (`global_load_lds_dwordx4`,
+// no VGPR destination) right after barrier 1, i.e. while the column wave runs its chains and
+// the cell waves would otherwise only wait -- the stamps of the plain kernel show the CU's memory
+// queue saturated during P1 and nearly idle in the other 40 % of a row.  fp64 has no registers
+// left for a classic prefetch (every such variant spilled); the DMA needs none.  What it needs
+// is LDS: t_1 rows 64 wide (halo kept apart in TH) and one more [nk][64] buffer for v, paid for
+// by single-buffering the 2-D rows.  Barriers 2 and 3 are LDS-only (inline asm): a
+// __syncthreads() would drain the DMA (hipcc waits vmcnt(0) at a workgroup fence while an
+// LDS-DMA is in flight); barrier 4 is a full one and is where the DMA must have landed.
+// Requirements checked by the launcher: rows are a multiple of 16 bytes, t_1 and v 16-byte
+// aligned, every cell wave owns whole DMA instructions (KPT % (64*sizeof(T)/... ) == 0), nk % KPT == 0.
+__device__ __forceinline__ void amt_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T, int KPT>
+__global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_march_dma_kernel(const AmtParams<T> p, const AmtMarchGrid g)
+{
+    extern __shared__ __align__(16) unsigned char amt_smem[];
+    const int nk = p.nk;
+    constexpr int TW = AMT_TW, N2D = AMT_N2D;
+    constexpr int EPL = 16 / (int)sizeof(T);      // elements per lane of one DMA instruction
+    constexpr int LPL = 64 / EPL;                 // lanes per level row (64 elements)
+    constexpr int LPI = 64 / LPL;                 // levels per DMA instruction
+    static_assert(KPT % LPI == 0, "a cell wave must own whole DMA instructions");
+    T *AP = reinterpret_cast<T *>(amt_smem);      // [nk][64]   dvdxi(i,k) (the column wave multiplies by dnw)
+    T *B  = AP + (size_t)nk * 64;                 // [nk][64]   ww increments, then ww(k+1)
+    T *T1 = B + (size_t)nk * 64;                  // [2][nk][64] t_1 rows (buffer = row parity)
+    T *V  = T1 + (size_t)2 * nk * 64;             // [nk][64]   v of row j+1
+    T *TH = V + (size_t)nk * 64;                  // [2][nk][2] i halo of the t_1 rows: left, right
+    T *D2 = TH + (size_t)4 * nk;                  // [N2D][66]  2-D inputs of the current row
+    T *DM = D2 + (size_t)N2D * TW;                // [64]
+    T *W0 = DM + 64;                              // [64]
+    T *S1 = W0 + 64;                              // dnw | fnm | fnp | rdnw
+    const T *s_dnw = S1, *s_fnm = S1 + nk, *s_fnp = S1 + 2 * nk, *s_rdnw = S1 + 3 * nk;
+    const int t1buf = nk * 64, thbuf = nk * 2;
+
+    const int lane = threadIdx.x & 63;
+    const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwav = (int)(blockDim.x >> 6);
+    const int nc   = nwav - 1;
+    const bool colw = (w == nc);
+    const unsigned vo = (unsigned)lane * (unsigned)sizeof(T);
+
+    int lid;
+    {
+        const int nx = 8, q = g.nwg / nx, r = g.nwg % nx;
+        const int x = blockIdx.x % nx, y = blockIdx.x / nx;
+        lid = x * q + (x < r ? x : r) + y;
+    }
+    const int tile = g.tile_lo + lid % g.ntile_i;
+    const int jblk = lid / g.ntile_i;
+
+    for (int e = threadIdx.x; e < 4 * nk; e += blockDim.x) {
+        const int which = e / nk, k = e % nk;
+        const T *src = which == 0 ? p.dnw : which == 1 ? p.fnm : which == 2 ? p.fnp : p.rdnw;
+        S1[e] = src[p.k1 + k];
+    }
+
+    const int ii   = tile * 64 + lane;
+    const bool act = (ii >= p.i0) && (ii <= p.i1);
+    const bool inmem = ii < p.idim;
+    const bool halo_r = (lane == 0) && (ii + 64 < p.idim);
+    const int ja   = p.j0 + jblk * g.jrows;
+    const int jb   = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
+
+    const long idim = p.idim, js = p.jstride;
+    const unsigned lev = (unsigned)idim * (unsigned)sizeof(T);
+    const unsigned row3 = (unsigned)js * (unsigned)sizeof(T);
+    const unsigned row2 = lev;
+    const long e2 = (long)ja * idim + (long)tile * 64;
+
+    auto d2_src = [&](int q) -> const T * {
+        switch (q) {
+        case 0: return p.msftx + e2;
+        case 1: return p.msfty + e2;
+        case 2: return p.muu + e2;
+        case 3: return p.msfuy + e2;
+        case 4: return p.muv + e2 + idim;
+        case 5: return p.msfvx_inv + e2 + idim;
+        default: return p.mu_tend + e2;
+        }
+    };
+
+    if (colw) {
+        // ===================== column wave (as in amt_march_kernel; D2 single-buffered) =====================
+        const T *wwin_b = p.ww + (long)ja * js + (long)p.k1 * idim + (long)tile * 64;
+        const T *mut_b = p.mut + e2;
+        T *mu_b = p.mu + e2, *mudf_b = p.mudf + e2, *muts_b = p.muts + e2, *muave_b = p.muave + e2;
+        const T dts = p.dts;
+#pragma unroll
+        for (int q = 0; q < N2D; ++q) {
+            const T *src = d2_src(q);
+            if (inmem) D2[q * TW + 1 + lane] = amt_ld(src, vo);
+            if (halo_r) D2[q * TW + TW - 1] = amt_ld(src + 64, vo);
+        }
+        __syncthreads();                           // S1, T1, TH, V, D2 staged
+
+        unsigned o3 = vo, o2 = vo;
+        for (int jj = ja; jj <= jb; ++jj, o3 += row3, o2 += row2) {
+            const bool more = (jj < jb);
+            T d2v[N2D], d2h[N2D];
+#pragma unroll
+            for (int q = 0; q < N2D; ++q) { d2v[q] = T(0); d2h[q] = T(0); }
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < N2D; ++q) {
+                    const T *src = d2_src(q);
+                    if (inmem) d2v[q] = amt_ld(src, o2 + row2);
+                    if (halo_r) d2h[q] = amt_ld(src + 64, o2 + row2);
+                }
+            }
+            T ww1in = T(0), mu_old = T(0), mut_v = T(0);
+            if (act) {
+                ww1in = amt_ld(wwin_b, o3);
+                mu_old = amt_ld(mu_b, o2);
+                mut_v = amt_ld(mut_b, o2);
+            }
+            const T mu_tend = D2[6 * TW + 1 + lane];
+            __syncthreads();                                     // 1: AP complete, D2/T1 row j no longer read
+            T dmdt = T(0);
+            {
+                int k = 0;
+                for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
+                    T a[AMT_CHAIN];
+#pragma unroll
+                    for (int q = 0; q < AMT_CHAIN; ++q) a[q] = s_dnw[k + q] * AP[(k + q) * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < AMT_CHAIN; ++q) dmdt = dmdt + a[q];
+                }
+                for (; k < nk; ++k) dmdt = dmdt + s_dnw[k] * AP[k * 64 + lane];
+            }
+            DM[lane] = dmdt;
+            W0[lane] = ww1in;
+            if (more) {                                          // install the 2-D row j+1
+#pragma unroll
+                for (int q = 0; q < N2D; ++q) {
+                    if (inmem) D2[q * TW + 1 + lane] = d2v[q];
+                    if (halo_r) D2[q * TW + TW - 1] = d2h[q];
+                }
+            }
+            amt_lds_barrier();                                   // 2: DM, W0 published
+            if (act) {
+                const T mu_new = mu_old + dts * (dmdt + mu_tend);
+                amt_st(mu_b, o2, mu_new);
+                amt_st(mudf_b, o2, (dmdt + mu_tend));
+                amt_st(muts_b, o2, mut_v + mu_new);
+                amt_st(muave_b, o2, T(.5) * ((T(1.) + p.epssm) * mu_new + (T(1.) - p.epssm) * mu_old));
+            }
+            amt_lds_barrier();                                   // 3: B (increments) complete
+            {
+                T wwu = ww1in;
+                int k = 0;
+                for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
+                    T b[AMT_CHAIN];
+#pragma unroll
+                    for (int q = 0; q < AMT_CHAIN; ++q) b[q] = B[(k + q) * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < AMT_CHAIN; ++q) { wwu = wwu - b[q]; B[(k + q) * 64 + lane] = wwu; }
+                }
+                for (; k < nk; ++k) { wwu = wwu - B[k * 64 + lane]; B[k * 64 + lane] = wwu; }
+            }
+            __syncthreads();                                     // 4
+        }
+    } else {
+        // ===================== cell waves =====================
+        const int kf = w * KPT;
+        const bool has_above = (kf + KPT < nk);
+        const T rdx = p.rdx, rdy = p.rdy, dts = p.dts;
+        const T hrdy = T(.5) * rdy, hrdx = T(.5) * rdx;
+        const long e3 = (long)ja * js + (long)(p.k1 + kf) * idim + (long)tile * 64;
+        const T *u_b = p.u + e3, *u1_b = p.u_1 + e3, *ft_b = p.ft + e3, *ww1_b = p.ww_1 + e3;
+        const T *v1n_b = p.v_1 + e3 + js;                                    // row j+1
+        const T *t1_b = p.t_1 + e3, *v_b = p.v + e3;                         // row ja (DMA sources advance by rows)
+        T *t_b = p.t + e3, *tave_b = p.t_ave + e3, *ww_b = p.ww + e3;
+
+        // DMA lane roles: lane -> (level within the instruction, 16-byte chunk of the 64-element row).
+        // Addresses are (wave-uniform base) + (32-bit per-lane offset), like every other access.
+        const int dl = lane / LPL;                                           // level within the instruction
+        const unsigned dvo = (unsigned)dl * lev + (unsigned)(lane % LPL) * 16u;
+        const bool dok = tile * 64 + (lane % LPL) * EPL < p.idim;            // chunk lies inside the memory row
+        // copies levels [kf .. kf+KPT) of j row (ja + rows) of `src` (uniform base at row ja) to lds
+        auto dma_rows = [&](const T *src, int rows, T *lds) {
+            const unsigned ro = dvo + (unsigned)rows * row3;                 // the row advance rides in the lane offset
+#pragma unroll
+            for (int q = 0; q < KPT / LPI; ++q) {
+                const char *ub = reinterpret_cast<const char *>(src) + (size_t)(q * LPI) * lev;
+                if (dok)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
+                                                     (__attribute__((address_space(3))) void *)(lds + (size_t)(kf + q * LPI) * 64),
+                                                     16, 0, 0);
+            }
+        };
+        // i halo of a t_1 row: per level the elements left of lane 0 and right of lane 63, DMA'd one
+        // dword per lane into TH[level][side] (2*DPE lanes per instruction, one instruction per level)
+        constexpr int DPE = (int)sizeof(T) / 4;                              // dwords per element
+        const int hside = lane / DPE;                                        // 0 left, 1 right (lanes < 2*DPE)
+        const bool hok = lane < 2 * DPE && (hside == 0 ? tile * 64 - 1 >= 0 : tile * 64 + 64 < p.idim);
+        const unsigned hvo = (unsigned)(hside ? 65 * (int)sizeof(T) : 0) + (unsigned)(lane % DPE) * 4u;   // from element -1
+        auto dma_halo = [&](const T *src, int rows, T *lds) {
+            const unsigned ro = hvo + (unsigned)rows * row3;
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                const char *ub = reinterpret_cast<const char *>(src - 1) + (size_t)m * lev;
+                if (hok)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
+                                                     (__attribute__((address_space(3))) void *)(lds + (size_t)(kf + m) * 2),
+                                                     4, 0, 0);
+            }
+        };
+
+        T vfm[KPT], vft[KPT];
+#pragma unroll
+        for (int m = 0; m < KPT; ++m) { vfm[m] = vft[m] = T(0); }
+
+        // ---- prologue: t_1 rows ja, ja+1 (+ halos) and v row ja+1 by DMA; j-face fluxes of row ja ----
+        dma_rows(t1_b, 0, T1);
+        dma_rows(t1_b, 1, T1 + t1buf);
+        dma_rows(v_b, 1, V);
+        dma_halo(t1_b, 0, TH);
+        dma_halo(t1_b, 1, TH + thbuf);
+        {
+            T muv_j = T(0), mvx_j = T(0);
+            if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                const unsigned om = vo + (unsigned)m * lev;
+                if (act) {
+                    const T vv = amt_ld(v_b, om);
+                    vfm[m] = vv + muv_j * amt_ld(p.v_1 + e3, om) * mvx_j;
+                    vft[m] = vv * (amt_ld(t1_b, om) + amt_ld(t1_b - js, om));
+                }
+            }
+        }
+        __syncthreads();                               // everything staged, DMA landed
+
+        unsigned o3 = vo;
+        for (int jj = ja; jj <= jb; ++jj, o3 += row3) {
+            T hf[KPT], tw[KPT];
+            T msfty = T(1), mu_tend = T(0), tw_above = T(0);
+            const int par = (jj - ja) & 1;
+            const T *T1c = T1 + par * t1buf;                         // t_1 row j
+            const T *T1n = T1 + (par ^ 1) * t1buf;                   // t_1 row j+1 (DMA'd during the previous row)
+            const T *THc = TH + par * thbuf;
+            const bool more = (jj < jb);
+
+            // ---------------- P1 ----------------
+            if (act) {
+                const T msftx = D2[0 * TW + 1 + lane];
+                msfty = D2[1 * TW + 1 + lane];
+                const T mm = msftx * msfty;
+                const T muu_i = D2[2 * TW + 1 + lane], muu_ip = D2[2 * TW + 2 + lane];
+                const T msfuy_i = D2[3 * TW + 1 + lane], msfuy_ip = D2[3 * TW + 2 + lane];
+                const T muv_p = D2[4 * TW + 1 + lane], mvx_p = D2[5 * TW + 1 + lane];
+                mu_tend = D2[6 * TW + 1 + lane];
+                if (has_above) {
+                    const int Ka = kf + KPT;
+                    tw_above = s_fnm[Ka] * T1c[Ka * 64 + lane] + s_fnp[Ka] * T1c[(Ka - 1) * 64 + lane];
+                }
+                const int ll = lane > 0 ? lane - 1 : 0, lr = lane < 63 ? lane + 1 : 63;
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    const unsigned om = o3 + (unsigned)m * lev;
+                    const int K = kf + m;
+                    const T v1n = amt_ld(v1n_b, om);
+                    const T uu = amt_ld(u_b, om), uup = amt_ld(u_b + 1, om);
+                    const T u1 = amt_ld(u1_b, om), u1p = amt_ld(u1_b + 1, om);
+                    const T vn = V[K * 64 + lane], t1n = T1n[K * 64 + lane];
+                    const T t1c = T1c[K * 64 + lane];
+                    const T t1l_in = T1c[K * 64 + ll], t1r_in = T1c[K * 64 + lr];
+                    const T t1l = lane == 0 ? THc[K * 2] : t1l_in;
+                    const T t1r = lane == 63 ? THc[K * 2 + 1] : t1r_in;
+                    const T vfm_n = vn + muv_p * v1n * mvx_p;
+                    const T d = mm * ( rdy * (vfm_n - vfm[m])
+                                     + rdx * ( (uup + muu_ip * u1p / msfuy_ip)
+                                             - (uu  + muu_i  * u1  / msfuy_i ) ));
+                    AP[K * 64 + lane] = d;                        // :142-146; dnw(k)*d is formed by the column wave
+                    const T vft_n = vn * (t1n + t1c);
+                    hf[m] = msftx * ( hrdy * (vft_n - vft[m])
+                                    + hrdx * ( uup * (t1r + t1c) - uu * (t1c + t1l) ) );
+                    const T t1km1 = (K > 0) ? T1c[(K > 0 ? K - 1 : 0) * 64 + lane] : T(0);
+                    tw[m] = s_fnm[K] * t1c + s_fnp[K] * t1km1;
+                    vfm[m] = vfm_n; vft[m] = vft_n;
+                }
+            }
+            __syncthreads();                                         // 1: AP complete; row j of T1/TH/V/D2 dead
+
+            if (more) {
+                // rows j+2 of t_1 (+ halo) and v for the next P1: no registers, lands before barrier 4
+                const int rows = jj - ja + 2;
+                dma_rows(t1_b, rows, T1 + par * t1buf);
+                dma_rows(v_b, rows, V);
+                dma_halo(t1_b, rows, TH + par * thbuf);
+            }
+            T told[KPT], ftk[KPT], w1[KPT];
+            T w1_above = T(0);
+            if (act) {
+                if (has_above) w1_above = amt_ld(ww1_b, o3 + (unsigned)KPT * lev);
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    const unsigned om = o3 + (unsigned)m * lev;
+                    told[m] = amt_ld(t_b, om);
+                    ftk[m] = amt_ld(ft_b, om);
+                    w1[m] = amt_ld(ww1_b, om);
+                }
+            }
+            amt_lds_barrier();                                       // 2: DM, W0 published (DMA keeps flying)
+            if (act) {
+                const T dmdt = DM[lane];
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    const int K = kf + m;
+                    B[K * 64 + lane] = s_dnw[K] * (dmdt + AP[K * 64 + lane] + mu_tend) / msfty;   // :161
+                }
+            }
+            amt_lds_barrier();                                       // 3: B (increments) complete
+            __syncthreads();                                         // 4: ww of the recurrence published; DMA landed
+
+            // ---------------- P3 ----------------
+            if (act) {
+                T wwu = (kf == 0) ? W0[lane] : B[(kf > 0 ? kf - 1 : 0) * 64 + lane];
+                T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    const unsigned om = o3 + (unsigned)m * lev;
+                    const int K = kf + m;
+                    const T wout = wwu - w1[m];
+                    amt_st_stream(ww_b, om, wout);
+                    T wd_n = T(0);
+                    const T wwu_n = B[K * 64 + lane];
+                    if (m + 1 < KPT) wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
+                    else if (has_above) wd_n = (wwu_n - w1_above) * tw_above;
+                    amt_st_stream(tave_b, om, told[m]);
+                    const T tb = told[m] + msfty * dts * ftk[m];
+                    amt_st_stream(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));
+                    wwu = wwu_n; wd_k = wd_n;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
 
@@ -559,9 +907,53 @@ static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &
     return hipGetLastError();
 }
 
+template <typename T> static size_t amt_march_dma_lds(int nk)
+{
+    // AP, B, T1[2], V: [nk][64]; TH [2][nk][2]; D2 [7][66]; DM, W0 [64]; S1 [4][nk]
+    return ((size_t)5 * nk * 64 + (size_t)4 * nk + AMT_N2D * AMT_TW + 128 + 4 * (size_t)nk) * sizeof(T);
+}
+
+template <typename T, int KPT>
+static bool amt_march_dma_ok(const AmtParams<T> &p)
+{
+    constexpr int EPL = 16 / (int)sizeof(T), LPI = 64 / (64 / EPL);
+    if (KPT % LPI != 0 || p.nk % KPT != 0) return false;
+    if (p.idim % EPL != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(p.t_1) | reinterpret_cast<uintptr_t>(p.v)) & 15u) return false;
+    if (amt_march_dma_lds<T>(p.nk) > 160 * 1024) return false;
+    return amt_env_int("AMT_MARCH_DMA", 1) != 0;
+}
+
+template <typename T, int KPT>
+static hipError_t amt_march_launch_dma(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g)
+{
+    if constexpr (KPT % (64 / (64 / (16 / (int)sizeof(T)))) == 0) {
+        const size_t lds = amt_march_dma_lds<T>(p.nk);
+        const int nw = p.nk / KPT + 1;
+        if (lds > 64 * 1024) {
+            static thread_local size_t granted[64] = {};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+            if (lds > granted[slot] || slot != dev) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_dma_kernel<T, KPT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                granted[slot] = lds;
+            }
+        }
+        hipLaunchKernelGGL((amt_march_dma_kernel<T, KPT>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
 template <typename T, int KPT>
 static hipError_t amt_march_launch_kpt(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, size_t lds)
 {
+    if (amt_march_dma_ok<T, KPT>(p) && !amt_env_int("AMT_MARCH_STAMP", 0))
+        return amt_march_launch_dma<T, KPT>(stream, p, g);
     return (p.nk % KPT == 0) ? amt_march_launch_full<T, KPT, true>(stream, p, g, lds)
                              : amt_march_launch_full<T, KPT, false>(stream, p, g, lds);
 }
