@@ -30,6 +30,8 @@
 //    A column's chains are summed exactly once, in order: bit-exact and no redundant LDS
 //    traffic (an earlier version let every wave redo both chains: LDS-bandwidth bound).
 //  * Expressions keep the Fortran association; built with -ffp-contract=off.
+//  * Two flavours of the same kernel: amt_march_kernel (general) and amt_march_dma_kernel, which
+//    additionally prefetches the next row's t_1 and v through LDS-DMA (see its header below).
 //
 // Reference semantics: module_small_step_em.f90:112-172 (mu, ww), :208-215 and
 // :217-250 (theta); the fusion of the three Fortran phases is legal because a
