@@ -127,14 +127,15 @@ class SlabStepper:
         if jte < jts:
             return
         if self.on_gpu:
-            call = self._bound.get((jts, jte))
+            key = (jts, jte, id(stream))
+            call = self._bound.get(key)
             if call is None:
                 args = self.patch.with_bounds(jts=jts, jte=jte).args()
                 binder = getattr(self.compute, "bind", None)
                 if binder is None:                   # a plain callable: marshal on every call
                     self.compute(*args, stream=stream, variant=self.variant)
                     return
-                call = self._bound[(jts, jte)] = binder(*args, stream=stream, variant=self.variant)
+                call = self._bound[key] = binder(*args, stream=stream, variant=self.variant)
             call()
         else:
             self.compute(*self.patch.with_bounds(jts=jts, jte=jte).args())
@@ -150,15 +151,22 @@ class SlabStepper:
         in_hi = jhi - (1 if self.above is not None else 0)
         if self.on_gpu and self.overlap:
             import torch
+            # comm stream: exchange, then the edge rows (they need nothing but the halos and the
+            # inputs).  main stream: the interior.  The small edge launches (one row each) then fill
+            # the CUs that the interior's last, partly filled round of workgroups leaves idle.
             self.comm_stream.wait_stream(self.main_stream)      # inputs of this sub-step are final
+            self._tile(in_lo, in_hi, self.main_stream)          # interior overlaps the exchange
             with torch.cuda.stream(self.comm_stream):
                 self.exchange_halos()                           # RCCL send/recv on the comm stream
-            self._tile(in_lo, in_hi, self.main_stream)          # interior overlaps the exchange
+                self._edges(jlo, jhi, self.comm_stream)
             self.main_stream.wait_stream(self.comm_stream)
         else:
             self.exchange_halos()
             self._tile(in_lo, in_hi, self.main_stream)
+            self._edges(jlo, jhi, self.main_stream)
+
+    def _edges(self, jlo, jhi, stream):
         if self.below is not None:
-            self._tile(jlo, min(jlo, jhi), self.main_stream)
+            self._tile(jlo, min(jlo, jhi), stream)
         if self.above is not None and (jhi > jlo or self.below is None):
-            self._tile(jhi, jhi, self.main_stream)
+            self._tile(jhi, jhi, stream)
