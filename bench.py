@@ -85,6 +85,24 @@ def verify_first_sweep(pkg, oracle, dev, gb, dims, dtype, seed, rank_rows):
     return True, ""
 
 
+def fp32_error_vs_fp64(pkg, oracle, dev, gb, dims, seed, rank_rows):
+    """BASELINE.json configs[4]: the fp32 run judged against the fp64 Fortran (oracle in fp64 on a
+    3-row slab of regenerated fp64 inputs).  Returns max over the outputs of max|fp32-fp64| / max|fp64|."""
+    S = pkg.synth
+    b = dev.bounds
+    jlo = (rank_rows[0] + rank_rows[1]) // 2
+    jhi = min(jlo + 2, rank_rows[1])
+    sb = gb.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
+    want = S.make_patch(sb, dev.config, dtype=np.float64, seed=seed, global_dims=dims)
+    oracle.advance_mu_t_omp(*want.args(), nthreads=min(3, jhi - jlo + 1))
+    worst = 0.0
+    for n in S.OUTPUTS:
+        got = dev.arrays[n][jlo - b.jms: jhi + 1 - b.jms].cpu().numpy().astype(np.float64)
+        w = want.arrays[n][1: 1 + (jhi - jlo + 1)]
+        worst = max(worst, float(np.abs(got - w).max() / np.abs(w).max()))
+    return worst
+
+
 def cpu_baseline(pkg, oracle, dims, dtype, seed, rows, seconds):
     """Oracle (C port of the Fortran), j-tiled over all host cores, on a j-slab sample."""
     S = pkg.synth
@@ -246,6 +264,7 @@ def main():
         dist.barrier()
 
     verified, why = None, ""
+    fp32_err = None
     oracle = None
     warm_done = 0
     if a.warmup > 0 and not a.no_verify:
@@ -254,6 +273,8 @@ def main():
         warm_done = 1
         torch.cuda.synchronize()
         verified, why = verify_first_sweep(pkg, oracle, dev, gb, dims, dtype, a.seed, (sb.jts, sb.jte))
+        if a.dtype == "f32" and rank == 0:
+            fp32_err = fp32_error_vs_fp64(pkg, oracle, dev, gb, dims, a.seed, (sb.jts, sb.jte))
     for _ in range(a.warmup - warm_done):
         stepper.step()
 
@@ -329,6 +350,10 @@ def main():
         }
         if why:
             out["verify_message"] = why
+        if fp32_err is not None:
+            out["fp32_vs_fp64_oracle"] = {"max_abs_err_over_field_scale": float(f"{fp32_err:.3e}"),
+                                          "stated_tolerance": 2e-5,
+                                          "within_tolerance": bool(fp32_err <= 2e-5)}
         if world == 1 and not a.no_cpu_baseline:
             oracle = oracle or g.load_oracle()
             out["cpu_baseline"] = cpu_baseline(pkg, oracle, dims, dtype, a.seed, a.cpu_rows, a.cpu_seconds)
