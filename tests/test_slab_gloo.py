@@ -103,3 +103,67 @@ def test_slab_bounds_partition_the_rows(pkg):
     assert rows == list(range(1, 38))
     with pytest.raises(ValueError):
         S.slab_bounds(S.domain_bounds(8, 3, 2), 0, 3)
+
+
+def _grid_worker(rank, world, port, shape, flags, pi, pj, sweeps, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as g
+        pkg, oracle = g.load_package(), g.load_oracle()
+        S = pkg.synth
+        ri, rj = rank % pi, rank // pi
+        pb = S.patch_bounds(S.domain_bounds(*shape), ri, rj, pi, pj)
+        host = S.make_patch(pb, pkg.GridConfig(**flags), seed=91, global_dims=shape)
+        arrays = {k: torch.from_numpy(v) for k, v in host.arrays.items()}
+        nan = float("nan")
+        b = pb
+        if rj < pj - 1:
+            for name in S.HALO_FROM_ABOVE:
+                arrays[name][-1].fill_(nan)
+        if rj > 0:
+            arrays["t_1"][0].fill_(nan)
+        if ri < pi - 1:
+            for name in pkg.patch.HALO_FROM_RIGHT:
+                arrays[name][..., b.ite - b.ims + 1].fill_(nan)
+        if ri > 0:
+            arrays["t_1"][..., b.its - b.ims - 1].fill_(nan)
+        patch = S.Patch(pb, host.config, arrays, host.rdx, host.rdy, host.dts, host.epssm, shape)
+
+        def compute(*args):
+            oracle.advance_mu_t(*[a.numpy() if isinstance(a, torch.Tensor) else a for a in args])
+
+        st = pkg.patch.GridStepper(patch, ri, rj, pi, pj, compute)
+        for _ in range(sweeps):
+            st.step()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), bounds=np.array(pb.as_tuple()),
+                 **{n: arrays[n].numpy() for n in S.OUTPUTS})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pi,pj,shape,flags", [
+    (2, 1, (21, 5, 6), dict()),
+    (2, 2, (17, 4, 9), dict(specified=True)),
+    (3, 2, (20, 3, 7), dict(nested=True, periodic_x=True)),
+])
+def test_2d_patches_reproduce_the_unsplit_domain(tmp_path, pi, pj, shape, flags):
+    """i x j decomposition: packed column halos + row halos, NaN-poisoned."""
+    sweeps, world = 2, pi * pj
+    mp.spawn(_grid_worker, args=(world, _free_port(), shape, flags, pi, pj, sweeps, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as g
+    pkg, oracle = g.load_package(), g.load_oracle()
+    S = pkg.synth
+    full = S.make_patch(S.domain_bounds(*shape), pkg.GridConfig(**flags), seed=91)
+    for _ in range(sweeps):
+        oracle.advance_mu_t(*full.args())
+    for rank in range(world):
+        r = np.load(tmp_path / f"rank{rank}.npz")
+        b = S.Bounds(*[int(x) for x in r["bounds"]])
+        for n in S.OUTPUTS:
+            mine = r[n][b.jts - b.jms: b.jte - b.jms + 1, ..., b.its - b.ims: b.ite - b.ims + 1]
+            want = full.arrays[n][b.jts: b.jte + 1, ..., b.its: b.ite + 1]        # global ims = jms = 0
+            assert np.array_equal(mine.view(np.uint8), want.view(np.uint8)), (rank, n)

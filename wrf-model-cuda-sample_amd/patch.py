@@ -170,3 +170,95 @@ class SlabStepper:
             self._tile(jlo, min(jlo, jhi), stream)
         if self.above is not None and (jhi > jlo or self.below is None):
             self._tile(jhi, jhi, stream)
+
+
+# i-direction halos (module_small_step_em.f90:145 reads u, u_1, muu, msfuy at i+1; :244-245 read
+# t_1 at i+1 and i-1)
+HALO_FROM_RIGHT = ("u", "u_1", "t_1", "muu", "msfuy")
+HALO_FROM_LEFT = ("t_1",)
+
+
+class GridStepper:
+    """advance_mu_t on patch (ri, rj) of a pi x pj decomposition in i AND j (SURVEY.md section 8f
+    row 4).  j halos are contiguous rows and travel in place as in SlabStepper; i halos are columns
+    (stride idim in memory), so they are packed into contiguous buffers, sent, and unpacked on
+    arrival.  No diagonal neighbours are needed: the stencil reads (i+-1, j) and (i, j+-1) only.
+    One launch per sweep after the exchange (no interior/edge split here: this decomposition is for
+    domains too small in j to be bandwidth-bound per GPU).  Ranks are row-major: rank = rj*pi + ri.
+    """
+
+    def __init__(self, patch: Patch, ri: int, rj: int, pi: int, pj: int, compute: Callable, *,
+                 group=None, variant: int = 0, stage_through_host: bool = False):
+        self.patch, self.ri, self.rj, self.pi, self.pj = patch, ri, rj, pi, pj
+        self.compute, self.group, self.variant = compute, group, variant
+        self.stage_through_host = stage_through_host
+        rank = lambda i, j: j * pi + i
+        self.left = rank(ri - 1, rj) if ri > 0 else None
+        self.right = rank(ri + 1, rj) if ri < pi - 1 else None
+        self.below = rank(ri, rj - 1) if rj > 0 else None
+        self.above = rank(ri, rj + 1) if rj < pj - 1 else None
+        b = patch.bounds
+        self.c_first, self.c_last = b.its - b.ims, b.ite - b.ims          # owned columns (memory index)
+        self.c_halo_l, self.c_halo_r = self.c_first - 1, self.c_last + 1
+        self.on_gpu = bool(getattr(patch.arrays["t_1"], "is_cuda", False))
+        self._call = None
+
+    def _col(self, name, c):
+        a = self.patch.arrays[name]
+        return a[..., c]                                   # (jdim, kdim) or (jdim,) strided view
+
+    def exchange_halos(self):
+        dist = _dist()
+        a = self.patch.arrays
+        jdim = self.patch.bounds.jdim
+        ops, unpack = [], []
+        host = self.stage_through_host and self.on_gpu
+
+        def send(t, peer, tag):
+            t = t.contiguous()
+            ops.append(dist.P2POp(dist.isend, t.cpu() if host else t, peer, self.group, tag))
+
+        def recv(view, peer, tag, packed):
+            if packed or host:
+                buf = view.new_empty(view.shape, device="cpu" if host else view.device)
+                unpack.append((view, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, peer, self.group, tag))
+            else:
+                ops.append(dist.P2POp(dist.irecv, view, peer, self.group, tag))
+
+        if self.below is not None:
+            for n, name in enumerate(HALO_FROM_ABOVE):
+                send(a[name][1], self.below, 10 + n)
+            recv(a["t_1"][0], self.below, 20, False)
+        if self.above is not None:
+            for n, name in enumerate(HALO_FROM_ABOVE):
+                recv(a[name][jdim - 1], self.above, 10 + n, False)
+            send(a["t_1"][jdim - 2], self.above, 20)
+        if self.left is not None:
+            for n, name in enumerate(HALO_FROM_RIGHT):     # my first column is their column ihi+1
+                send(self._col(name, self.c_first), self.left, 30 + n)
+            recv(self._col("t_1", self.c_halo_l), self.left, 40, True)
+        if self.right is not None:
+            for n, name in enumerate(HALO_FROM_RIGHT):
+                recv(self._col(name, self.c_halo_r), self.right, 30 + n, True)
+            send(self._col("t_1", self.c_last), self.right, 40)
+        if not ops:
+            return
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for view, buf in unpack:
+            view.copy_(buf)
+
+    def step(self):
+        self.exchange_halos()
+        args = self.patch.args()
+        if self.on_gpu:
+            if self._call is None:
+                binder = getattr(self.compute, "bind", None)
+                if binder is None:
+                    self.compute(*args, variant=self.variant)
+                    return
+                self._call = binder(*args, variant=self.variant)
+            self._call()
+        else:
+            self.compute(*args)

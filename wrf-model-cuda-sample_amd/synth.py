@@ -117,6 +117,27 @@ def slab_bounds(g: Bounds, rank: int, world: int) -> Bounds:
     return g.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
 
 
+def patch_bounds(g: Bounds, ri: int, rj: int, pi: int, pj: int, *, align_elems: int = 1) -> Bounds:
+    """Patch (ri, rj) of a pi x pj decomposition of the domain ``g`` in i and j (SURVEY.md section 8f
+    row 4: domains whose j extent is too small for one slab per GPU).  Computed columns ids..ide-1
+    and rows jds..jde-1 are split contiguously; memory holds the patch plus one halo cell on every
+    side (``align_elems`` > 1 pads the i memory so that i = its starts an aligned boundary)."""
+    ncol, nrow = g.ide - g.ids, g.jde - g.jds
+    if not (0 <= ri < pi and 0 <= rj < pj) or ncol < pi or nrow < pj:
+        raise ValueError("bad patch index or domain too small for this decomposition")
+    ilo = g.ids + (ncol * ri) // pi
+    ihi = g.ids + (ncol * (ri + 1)) // pi - 1
+    jlo = g.jds + (nrow * rj) // pj
+    jhi = g.jds + (nrow * (rj + 1)) // pj - 1
+    if align_elems > 1:
+        ims = ilo - align_elems
+        idim = -(-(ihi + 1 - ims + 1) // align_elems) * align_elems
+        ime = ims + idim - 1
+    else:
+        ims, ime = ilo - 1, ihi + 1
+    return g.replace(ims=ims, ime=ime, its=ilo, ite=ihi, jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
+
+
 @dataclass
 class Patch:
     """One patch's arguments of advance_mu_t: bounds, flags, scalars and the 26 arrays
