@@ -89,7 +89,9 @@ def domain_bounds(ni: int, nk: int, nj: int, *, aligned: bool = False, align_ele
     section 8 convention: ids=jds=kds=1, ide=NI+1, jde=NJ+1, kde=NK+1, tile = domain.
     ``aligned=False``: minimal memory (0:NI+1, 1:NK+1, 0:NJ+1).
     ``aligned=True`` : i memory padded so that i = its sits ``align_elems`` elements into
-    a row and rows are a multiple of ``align_elems`` long (the resident device layout)."""
+    a row and rows are a multiple of ``align_elems`` long (the resident device layout).  32
+    elements (256 B in fp64) measured faster than 64 (whole i-tiles, but a row stride of 4224
+    elements): 16.0 vs 16.5 ms per 4096x60x4096 sweep, interleaved in one process."""
     if aligned:
         ims = 1 - align_elems
         idim = -(-(ni + 1 - ims + 1) // align_elems) * align_elems
