@@ -487,7 +487,9 @@ __device__ __forceinline__ void amt_lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename T, int KPT>
+// XD: how many MORE input rows ride the DMA when LDS allows (fp32, or fp64 with nk <= ~44):
+//   0: t_1, v   1: + v_1 (row j+2)   2: + u (row j+1, with its i+1 halo)   3: + u_1  -> no global load left in P1
+template <typename T, int KPT, int XD>
 __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_march_dma_kernel(const AmtParams<T> p, const AmtMarchGrid g)
 {
     extern __shared__ __align__(16) unsigned char amt_smem[];
@@ -502,7 +504,11 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
     T *T1 = B + (size_t)nk * 64;                  // [2][nk][64] t_1 rows (buffer = row parity)
     T *V  = T1 + (size_t)2 * nk * 64;             // [nk][64]   v of row j+1
     T *TH = V + (size_t)nk * 64;                  // [2][nk][2] i halo of the t_1 rows: left, right
-    T *D2 = TH + (size_t)4 * nk;                  // [N2D][66]  2-D inputs of the current row
+    T *V1 = TH + (size_t)4 * nk;                  // [nk][64]   v_1 of row j+1            (XD >= 1)
+    T *U  = V1 + (XD >= 1 ? (size_t)nk * 64 : 0); // [nk][64]   u of row j                (XD >= 2)
+    T *U1 = U + (XD >= 2 ? (size_t)nk * 64 : 0);  // [nk][64]   u_1 of row j              (XD >= 3)
+    T *UH = U1 + (XD >= 3 ? (size_t)nk * 64 : 0); // [2][nk]    element i+64 of the u / u_1 rows (XD >= 2)
+    T *D2 = UH + (XD >= 2 ? (size_t)2 * nk : 0);  // [N2D][66]  2-D inputs of the current row
     T *DM = D2 + (size_t)N2D * TW;                // [64]
     T *W0 = DM + 64;                              // [64]
     T *S1 = W0 + 64;                              // dnw | fnm | fnp | rdnw
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
         const long e3 = (long)ja * js + (long)(p.k1 + kf) * idim + (long)tile * 64;
         const T *u_b = p.u + e3, *u1_b = p.u_1 + e3, *ft_b = p.ft + e3, *ww1_b = p.ww_1 + e3;
         const T *v1n_b = p.v_1 + e3 + js;                                    // row j+1
-        const T *t1_b = p.t_1 + e3, *v_b = p.v + e3;                         // row ja (DMA sources advance by rows)
+        const T *t1_b = p.t_1 + e3, *v_b = p.v + e3, *v1_b = p.v_1 + e3;      // row ja (DMA sources advance by rows)
         T *t_b = p.t + e3, *tave_b = p.t_ave + e3, *ww_b = p.ww + e3;
 
         // DMA lane roles: lane -> (level within the instruction, 16-byte chunk of the 64-element row).
@@ -683,16 +689,38 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
             }
         };
 
+        // element i+64 (right of lane 63) of a u / u_1 row: DPE lanes, one dword each, into UH[which][level]
+        const bool uok = lane < DPE && tile * 64 + 64 < p.idim;
+        const unsigned uvo = 64u * (unsigned)sizeof(T) + (unsigned)(lane % DPE) * 4u;
+        auto dma_uhalo = [&](const T *src, int rows, T *lds) {
+            const unsigned ro = uvo + (unsigned)rows * row3;
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                const char *ub = reinterpret_cast<const char *>(src) + (size_t)m * lev;
+                if (uok)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
+                                                     (__attribute__((address_space(3))) void *)(lds + (size_t)(kf + m)),
+                                                     4, 0, 0);
+            }
+        };
+        // the DMA set of one row advance: what P1 of row (ja + r) needs beyond what is already in LDS
+        auto dma_next = [&](int r, T *t1dst, T *thdst) {
+            dma_rows(t1_b, r + 1, t1dst);                                    // t_1(j+1) of that row
+            dma_rows(v_b, r + 1, V);                                         // v(j+1)
+            dma_halo(t1_b, r + 1, thdst);
+            if (XD >= 1) dma_rows(v1_b, r + 1, V1);                          // v_1(j+1)
+            if (XD >= 2) { dma_rows(u_b, r, U); dma_uhalo(u_b, r, UH); }     // u(j), u(i+64)
+            if (XD >= 3) { dma_rows(u1_b, r, U1); dma_uhalo(u1_b, r, UH + nk); }
+        };
+
         T vfm[KPT], vft[KPT];
 #pragma unroll
         for (int m = 0; m < KPT; ++m) { vfm[m] = vft[m] = T(0); }
 
-        // ---- prologue: t_1 rows ja, ja+1 (+ halos) and v row ja+1 by DMA; j-face fluxes of row ja ----
+        // ---- prologue: everything P1 of row ja needs, by DMA; j-face fluxes of row ja ----
         dma_rows(t1_b, 0, T1);
-        dma_rows(t1_b, 1, T1 + t1buf);
-        dma_rows(v_b, 1, V);
         dma_halo(t1_b, 0, TH);
-        dma_halo(t1_b, 1, TH + thbuf);
+        dma_next(0, T1 + t1buf, TH + thbuf);
         {
             T muv_j = T(0), mvx_j = T(0);
             if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
@@ -736,9 +764,18 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 for (int m = 0; m < KPT; ++m) {
                     const unsigned om = o3 + (unsigned)m * lev;
                     const int K = kf + m;
-                    const T v1n = amt_ld(v1n_b, om);
-                    const T uu = amt_ld(u_b, om), uup = amt_ld(u_b + 1, om);
-                    const T u1 = amt_ld(u1_b, om), u1p = amt_ld(u1_b + 1, om);
+                    T v1n, uu, uup, u1, u1p;
+                    if (XD >= 1) v1n = V1[K * 64 + lane]; else v1n = amt_ld(v1n_b, om);
+                    if (XD >= 2) {
+                        uu = U[K * 64 + lane];
+                        const T up_in = U[K * 64 + lr];
+                        uup = lane == 63 ? UH[K] : up_in;
+                    } else { uu = amt_ld(u_b, om); uup = amt_ld(u_b + 1, om); }
+                    if (XD >= 3) {
+                        u1 = U1[K * 64 + lane];
+                        const T up_in = U1[K * 64 + lr];
+                        u1p = lane == 63 ? UH[nk + K] : up_in;
+                    } else { u1 = amt_ld(u1_b, om); u1p = amt_ld(u1_b + 1, om); }
                     const T vn = V[K * 64 + lane], t1n = T1n[K * 64 + lane];
                     const T t1c = T1c[K * 64 + lane];
                     const T t1l_in = T1c[K * 64 + ll], t1r_in = T1c[K * 64 + lr];
@@ -759,13 +796,8 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
             }
             __syncthreads();                                         // 1: AP complete; row j of T1/TH/V/D2 dead
 
-            if (more) {
-                // rows j+2 of t_1 (+ halo) and v for the next P1: no registers, lands before barrier 4
-                const int rows = jj - ja + 2;
-                dma_rows(t1_b, rows, T1 + par * t1buf);
-                dma_rows(v_b, rows, V);
-                dma_halo(t1_b, rows, TH + par * thbuf);
-            }
+            if (more)   // what the next row's P1 needs: no registers, lands before barrier 4
+                dma_next(jj - ja + 1, T1 + par * t1buf, TH + par * thbuf);
             T told[KPT], ftk[KPT], w1[KPT];
             T w1_above = T(0);
             if (act) {
@@ -909,10 +941,11 @@ static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &
     return hipGetLastError();
 }
 
-template <typename T> static size_t amt_march_dma_lds(int nk)
+template <typename T> static size_t amt_march_dma_lds(int nk, int xd)
 {
-    // AP, B, T1[2], V: [nk][64]; TH [2][nk][2]; D2 [7][66]; DM, W0 [64]; S1 [4][nk]
-    return ((size_t)5 * nk * 64 + (size_t)4 * nk + AMT_N2D * AMT_TW + 128 + 4 * (size_t)nk) * sizeof(T);
+    // AP, B, T1[2], V (+ V1, U, U1): [nk][64]; TH [2][nk][2] (+ UH [2][nk]); D2 [7][66]; DM, W0 [64]; S1 [4][nk]
+    return ((size_t)(5 + xd) * nk * 64 + (size_t)4 * nk + (xd >= 2 ? (size_t)2 * nk : 0)
+            + AMT_N2D * AMT_TW + 128 + 4 * (size_t)nk) * sizeof(T);
 }
 
 template <typename T, int KPT>
@@ -921,31 +954,55 @@ static bool amt_march_dma_ok(const AmtParams<T> &p)
     constexpr int EPL = 16 / (int)sizeof(T), LPI = 64 / (64 / EPL);
     if (KPT % LPI != 0 || p.nk % KPT != 0) return false;
     if (p.idim % EPL != 0) return false;
-    if ((reinterpret_cast<uintptr_t>(p.t_1) | reinterpret_cast<uintptr_t>(p.v)) & 15u) return false;
-    if (amt_march_dma_lds<T>(p.nk) > 160 * 1024) return false;
+    if ((reinterpret_cast<uintptr_t>(p.t_1) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.v_1)
+         | reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.u_1)) & 15u) return false;
+    if (amt_march_dma_lds<T>(p.nk, 0) > 160 * 1024) return false;
     return amt_env_int("AMT_MARCH_DMA", 1) != 0;
+}
+
+template <typename T, int KPT, int XD>
+static hipError_t amt_march_launch_dma_xd(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g)
+{
+    const size_t lds = amt_march_dma_lds<T>(p.nk, XD);
+    const int nw = p.nk / KPT + 1;
+    if (lds > 64 * 1024) {
+        static thread_local size_t granted[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+        if (lds > granted[slot] || slot != dev) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_dma_kernel<T, KPT, XD>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            granted[slot] = lds;
+        }
+    }
+    hipLaunchKernelGGL((amt_march_dma_kernel<T, KPT, XD>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
+    return hipGetLastError();
 }
 
 template <typename T, int KPT>
 static hipError_t amt_march_launch_dma(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g)
 {
     if constexpr (KPT % (64 / (64 / (16 / (int)sizeof(T)))) == 0) {
-        const size_t lds = amt_march_dma_lds<T>(p.nk);
-        const int nw = p.nk / KPT + 1;
-        if (lds > 64 * 1024) {
-            static thread_local size_t granted[64] = {};
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            const int slot = (dev >= 0 && dev < 64) ? dev : 0;
-            if (lds > granted[slot] || slot != dev) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_dma_kernel<T, KPT>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-                granted[slot] = lds;
-            }
+        // as many inputs through the DMA as LDS allows -- where measured to pay: all of them in fp32
+        // (4096x60x4096: 8.4 vs 9.3 ms), v_1 only in fp64 (the u/u_1 reads from LDS cost ~10 more live
+        // VGPRs and spill: nk 40: 11.3 vs 12.5 ms) and whenever u fits but u_1 does not (XD 2 never won)
+        int xd = 3;
+        while (xd > 0 && amt_march_dma_lds<T>(p.nk, xd) > 160 * 1024) --xd;
+        if (sizeof(T) == 8 && xd > 1) xd = 1;
+        if (xd == 2) xd = 1;
+        const int cap = amt_env_int("AMT_MARCH_XD", -1);
+        if (cap >= 0) {
+            xd = cap > 3 ? 3 : cap;
+            while (xd > 0 && amt_march_dma_lds<T>(p.nk, xd) > 160 * 1024) --xd;
         }
-        hipLaunchKernelGGL((amt_march_dma_kernel<T, KPT>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
-        return hipGetLastError();
+        switch (xd) {
+        case 3:  return amt_march_launch_dma_xd<T, KPT, 3>(stream, p, g);
+        case 2:  return amt_march_launch_dma_xd<T, KPT, 2>(stream, p, g);
+        case 1:  return amt_march_launch_dma_xd<T, KPT, 1>(stream, p, g);
+        default: return amt_march_launch_dma_xd<T, KPT, 0>(stream, p, g);
+        }
     } else {
         return hipErrorNotSupported;
     }
