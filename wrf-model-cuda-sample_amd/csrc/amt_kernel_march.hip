@@ -480,8 +480,9 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
 // by single-buffering the 2-D rows.  Barriers 2 and 3 are LDS-only (inline asm): a
 // __syncthreads() would drain the DMA (hipcc waits vmcnt(0) at a workgroup fence while an
 // LDS-DMA is in flight); barrier 4 is a full one and is where the DMA must have landed.
-// Requirements checked by the launcher: rows are a multiple of 16 bytes, t_1 and v 16-byte
-// aligned, every cell wave owns whole DMA instructions (KPT % (64*sizeof(T)/... ) == 0), nk % KPT == 0.
+// Requirements checked by the launcher (amt_march_dma_ok): rows are a multiple of 16 bytes, the
+// DMA'd arrays are 16-byte aligned, nk % KPT == 0 and every cell wave owns whole DMA instructions
+// (one instruction moves 64*16 bytes = 2 levels in fp64, 4 in fp32), and the LDS budget holds.
 __device__ __forceinline__ void amt_lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
