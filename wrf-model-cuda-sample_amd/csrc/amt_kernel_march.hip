@@ -500,9 +500,13 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
     constexpr int LPL = 64 / EPL;                 // lanes per level row (64 elements)
     constexpr int LPI = 64 / LPL;                 // levels per DMA instruction
     static_assert(KPT % LPI == 0, "a cell wave must own whole DMA instructions");
-    T *AP = reinterpret_cast<T *>(amt_smem);      // [nk][64]   dvdxi(i,k) (the column wave multiplies by dnw)
-    T *B  = AP + (size_t)nk * 64;                 // [nk][64]   ww increments, then ww(k+1)
-    T *T1 = B + (size_t)nk * 64;                  // [2][nk][64] t_1 rows (buffer = row parity)
+    // AB[k][lane] goes through three lives per row: dvdxi(i,k) (P1 .. barrier 2), the ww increment
+    // of level k (barrier 2 .. 3), ww(k) of the recurrence :161 (barrier 4 .. P3).  A cell wave
+    // only ever reads its OWN slots after barrier 2, so the next row's P1 may overwrite them
+    // without another barrier; the value it needs from the wave above is rebuilt from its own
+    // last increment, kept in a register (the same subtraction the column wave performs).
+    T *AB = reinterpret_cast<T *>(amt_smem);      // [nk][64]
+    T *T1 = AB + (size_t)nk * 64;                 // [2][nk][64] t_1 rows (buffer = row parity)
     T *V  = T1 + (size_t)2 * nk * 64;             // [nk][64]   v of row j+1
     T *TH = V + (size_t)nk * 64;                  // [2][nk][2] i halo of the t_1 rows: left, right
     T *V1 = TH + (size_t)4 * nk;                  // [nk][64]   v_1 of row j+1            (XD >= 1)
@@ -511,8 +515,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
     T *UH = U1 + (XD >= 3 ? (size_t)nk * 64 : 0); // [2][nk]    element i+64 of the u / u_1 rows (XD >= 2)
     T *D2 = UH + (XD >= 2 ? (size_t)2 * nk : 0);  // [N2D][66]  2-D inputs of the current row
     T *DM = D2 + (size_t)N2D * TW;                // [64]
-    T *W0 = DM + 64;                              // [64]
-    T *S1 = W0 + 64;                              // dnw | fnm | fnp | rdnw
+    T *S1 = DM + 64;                              // dnw | fnm | fnp | rdnw
     const T *s_dnw = S1, *s_fnm = S1 + nk, *s_fnp = S1 + 2 * nk, *s_rdnw = S1 + 3 * nk;
     const int t1buf = nk * 64, thbuf = nk * 2;
 
@@ -605,14 +608,13 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
                     T a[AMT_CHAIN];
 #pragma unroll
-                    for (int q = 0; q < AMT_CHAIN; ++q) a[q] = s_dnw[k + q] * AP[(k + q) * 64 + lane];
+                    for (int q = 0; q < AMT_CHAIN; ++q) a[q] = s_dnw[k + q] * AB[(k + q) * 64 + lane];
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) dmdt = dmdt + a[q];
                 }
-                for (; k < nk; ++k) dmdt = dmdt + s_dnw[k] * AP[k * 64 + lane];
+                for (; k < nk; ++k) dmdt = dmdt + s_dnw[k] * AB[k * 64 + lane];
             }
             DM[lane] = dmdt;
-            W0[lane] = ww1in;
             if (more) {                                          // install the 2-D row j+1
 #pragma unroll
                 for (int q = 0; q < N2D; ++q) {
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                     if (halo_r) D2[q * TW + TW - 1] = d2h[q];
                 }
             }
-            amt_lds_barrier();                                   // 2: DM, W0 published
+            amt_lds_barrier();                                   // 2: DM published
             if (act) {
                 const T mu_new = mu_old + dts * (dmdt + mu_tend);
                 amt_st(mu_b, o2, mu_new);
@@ -628,18 +630,18 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 amt_st(muts_b, o2, mut_v + mu_new);
                 amt_st(muave_b, o2, T(.5) * ((T(1.) + p.epssm) * mu_new + (T(1.) - p.epssm) * mu_old));
             }
-            amt_lds_barrier();                                   // 3: B (increments) complete
+            amt_lds_barrier();                                   // 3: AB holds the increments
             {
-                T wwu = ww1in;
+                T wwu = ww1in;                                   // AB[k] <- ww(k), the value BEFORE increment k
                 int k = 0;
                 for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
                     T b[AMT_CHAIN];
 #pragma unroll
-                    for (int q = 0; q < AMT_CHAIN; ++q) b[q] = B[(k + q) * 64 + lane];
+                    for (int q = 0; q < AMT_CHAIN; ++q) b[q] = AB[(k + q) * 64 + lane];
 #pragma unroll
-                    for (int q = 0; q < AMT_CHAIN; ++q) { wwu = wwu - b[q]; B[(k + q) * 64 + lane] = wwu; }
+                    for (int q = 0; q < AMT_CHAIN; ++q) { AB[(k + q) * 64 + lane] = wwu; wwu = wwu - b[q]; }
                 }
-                for (; k < nk; ++k) { wwu = wwu - B[k * 64 + lane]; B[k * 64 + lane] = wwu; }
+                for (; k < nk; ++k) { const T bk = AB[k * 64 + lane]; AB[k * 64 + lane] = wwu; wwu = wwu - bk; }
             }
             __syncthreads();                                     // 4
         }
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                     const T d = mm * ( rdy * (vfm_n - vfm[m])
                                      + rdx * ( (uup + muu_ip * u1p / msfuy_ip)
                                              - (uu  + muu_i  * u1  / msfuy_i ) ));
-                    AP[K * 64 + lane] = d;                        // :142-146; dnw(k)*d is formed by the column wave
+                    AB[K * 64 + lane] = d;                        // :142-146; dnw(k)*d is formed by the column wave
                     const T vft_n = vn * (t1n + t1c);
                     hf[m] = msftx * ( hrdy * (vft_n - vft[m])
                                     + hrdx * ( uup * (t1r + t1c) - uu * (t1c + t1l) ) );
@@ -811,21 +813,24 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                     w1[m] = amt_ld(ww1_b, om);
                 }
             }
-            amt_lds_barrier();                                       // 2: DM, W0 published (DMA keeps flying)
+            amt_lds_barrier();                                       // 2: DM published (DMA keeps flying)
+            T inc_last = T(0);                                      // my top level's increment (:161)
             if (act) {
                 const T dmdt = DM[lane];
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
                     const int K = kf + m;
-                    B[K * 64 + lane] = s_dnw[K] * (dmdt + AP[K * 64 + lane] + mu_tend) / msfty;   // :161
+                    const T inc = s_dnw[K] * (dmdt + AB[K * 64 + lane] + mu_tend) / msfty;   // :161
+                    AB[K * 64 + lane] = inc;
+                    if (m == KPT - 1) inc_last = inc;
                 }
             }
-            amt_lds_barrier();                                       // 3: B (increments) complete
+            amt_lds_barrier();                                       // 3: AB holds the increments
             __syncthreads();                                         // 4: ww of the recurrence published; DMA landed
 
             // ---------------- P3 ----------------
             if (act) {
-                T wwu = (kf == 0) ? W0[lane] : B[(kf > 0 ? kf - 1 : 0) * 64 + lane];
+                T wwu = AB[kf * 64 + lane];                          // ww of :161 at my first level
                 T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                     const T wout = wwu - w1[m];
                     amt_st_stream(ww_b, om, wout);
                     T wd_n = T(0);
-                    const T wwu_n = B[K * 64 + lane];
+                    const T wwu_n = (m + 1 < KPT) ? AB[(m + 1 < KPT ? K + 1 : K) * 64 + lane] : wwu - inc_last;
                     if (m + 1 < KPT) wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
                     else if (has_above) wd_n = (wwu_n - w1_above) * tw_above;
                     amt_st_stream(tave_b, om, told[m]);
@@ -944,9 +949,9 @@ static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &
 
 template <typename T> static size_t amt_march_dma_lds(int nk, int xd)
 {
-    // AP, B, T1[2], V (+ V1, U, U1): [nk][64]; TH [2][nk][2] (+ UH [2][nk]); D2 [7][66]; DM, W0 [64]; S1 [4][nk]
-    return ((size_t)(5 + xd) * nk * 64 + (size_t)4 * nk + (xd >= 2 ? (size_t)2 * nk : 0)
-            + AMT_N2D * AMT_TW + 128 + 4 * (size_t)nk) * sizeof(T);
+    // AB, T1[2], V (+ V1, U, U1): [nk][64]; TH [2][nk][2] (+ UH [2][nk]); D2 [7][66]; DM [64]; S1 [4][nk]
+    return ((size_t)(4 + xd) * nk * 64 + (size_t)4 * nk + (xd >= 2 ? (size_t)2 * nk : 0)
+            + AMT_N2D * AMT_TW + 64 + 4 * (size_t)nk) * sizeof(T);
 }
 
 template <typename T, int KPT>
