@@ -71,7 +71,11 @@ int amt_device_count(void);               /* number of visible HIP devices, 0 if
  * (1) One-shot drop-ins: HOST arrays in, HOST arrays out.  Replaces the body of
  *     the Fortran routine (module_small_step_em.f90:7-252) and the CUDA host
  *     wrapper (advance_mu_t_no_async.cu:35-424): allocate, upload, launch,
- *     download, free -- on the current HIP device.
+ *     download, free -- on the current HIP device.  Of ww, t and t_ave only the
+ *     cells the Fortran assigns (i_start..i_end, 1..kte-1, j_start..j_end) are
+ *     written back; t_ave and the levels above 1 of ww are outputs only and are
+ *     not uploaded.  The 2-D outputs come back as whole rows j_start..j_end
+ *     with their cells outside i_start..i_end unchanged.
  * ------------------------------------------------------------------------ */
 int amt_advance_mu_t_f32(
     float *ww, const float *ww_1, const float *u, const float *u_1,
@@ -107,9 +111,10 @@ int amt_advance_mu_t_f64(
 
 /* Page-lock / release a host array (hipHostRegister).  When all ten 3-D arrays of a one-shot
  * call are page-locked (by these, or allocated pinned by the caller as the reference driver
- * does, advance_mu_t_driver.cu:97-167) the call streams the window in j chunks over two HIP
- * streams so that H2D, kernel and D2H overlap; with pageable arrays it copies synchronously
- * in one piece like the reference wrapper.  Pin once, outside the time loop. */
+ * does, advance_mu_t_driver.cu:97-167) the call streams the window in j chunks through an
+ * upload, a compute and a download stream so that both directions of the host link and the
+ * kernels overlap; with pageable arrays it copies synchronously in one piece like the
+ * reference wrapper.  Pin once, outside the time loop. */
 int amt_host_pin(void *ptr, size_t bytes);
 int amt_host_unpin(void *ptr);
 

@@ -6,6 +6,7 @@
 // free), the device-resident drop-in, the resident domain handle and the
 // synthetic-input fill.  There is deliberately no CPU compute path in this file.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -206,15 +207,19 @@ struct DeviceArena {
 };
 struct StreamGuard {
     hipStream_t s = nullptr;
-    ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
+    ~StreamGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } }
+};
+struct EventGuard {
+    hipEvent_t e = nullptr;
+    ~EventGuard() { if (e) (void)hipEventDestroy(e); }
 };
 }  // namespace
 
 // Streamed one-shot: the window's j rows are cut into chunks; chunk c runs
 //   H2D (its rows + one halo row each side of the five arrays the stencil reads across
 //   rows) -> kernel -> D2H (its rows of the seven outputs)
-// on stream c % 2 with its own set of device buffers, so the transfers of one chunk overlap
-// the kernel and the opposite-direction transfer of the other.  That only pays when the host
+// through device buffer set c % 2, the three stages on an upload, a compute and a download
+// stream, so that both directions of the host link stay busy while the kernels run.  That only pays when the host
 // arrays are page-locked (amt_host_pin / hipHostRegister / hipHostMalloc by the caller, once,
 // like the reference driver's cudaHostAlloc, advance_mu_t_driver.cu:97-167): copies from
 // pageable memory are staged synchronously, and pinning inside the call costs more than it
@@ -272,8 +277,10 @@ static int amt_host_call(const AmtArgs<T> &h)
     const int nset = nchunk > 1 ? 2 : 1;
     const size_t crow = (size_t)rows + 2;                     // device rows per buffer set
 
-    // every array, OUT ones included (contents outside the window and level kte must survive,
-    // cf. advance_mu_t_no_async.cu:259,270-272)
+    // 2-D OUT arrays are uploaded too (contents outside the window must survive a whole-row
+    // download, cf. advance_mu_t_no_async.cu:259,270-272); the 3-D outputs come back as window-only
+    // strided copies instead, which saves the upload of t_ave and of all but level 1 of ww
+    enum { F_WW = 0, F_T_AVE = 15 };
     struct Item { const T *host; int rank; bool halo; bool out; };
     const Item items[26] = {
         {h.ww, 3, false, true}, {h.ww_1, 3, false, false}, {h.u, 3, false, false}, {h.u_1, 3, false, false},
@@ -285,8 +292,15 @@ static int amt_host_call(const AmtArgs<T> &h)
         {h.msfvx_inv, 2, true, false}, {h.msftx, 2, false, false}, {h.msfty, 2, false, false},
     };
 
+    const bool trace = getenv("AMT_STREAM_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    // 3-D arrays: nset buffer sets of rows+2 rows; 2-D arrays: the window's rows +-1, once for
+    // the whole call (they are ~1/NK of the data, and usually pageable: a pageable copy blocks
+    // the host, which inside the chunk loop would serialise the whole pipeline)
+    const size_t wrow = (size_t)nj + 2;
     DeviceArena arena;
-    arena.size = (size_t)nset * (10 * (r3 * crow * sizeof(T) + 256) + 12 * (r2 * crow * sizeof(T) + 256))
+    arena.size = (size_t)nset * 10 * (r3 * crow * sizeof(T) + 256) + 12 * (r2 * wrow * sizeof(T) + 256)
                  + 4 * (n1 * sizeof(T) + 256);
     if (hipMalloc((void **)&arena.base, arena.size) != hipSuccess) {
         (void)hipGetLastError();
@@ -297,63 +311,100 @@ static int amt_host_call(const AmtArgs<T> &h)
     for (int f = 0; f < 26; ++f) {
         if (items[f].rank == 1) {
             dev[0][f] = dev[1][f] = static_cast<T *>(arena.take(n1 * sizeof(T)));
+        } else if (items[f].rank == 2) {
+            dev[0][f] = dev[1][f] = static_cast<T *>(arena.take(r2 * wrow * sizeof(T)));   // row 0 <-> j_start-1
         } else {
-            const size_t n = (items[f].rank == 3 ? r3 : r2) * crow;
-            for (int s = 0; s < nset; ++s) dev[s][f] = static_cast<T *>(arena.take(n * sizeof(T)));
+            for (int s = 0; s < nset; ++s) dev[s][f] = static_cast<T *>(arena.take(r3 * crow * sizeof(T)));
             if (nset == 1) dev[1][f] = dev[0][f];
         }
     }
-    StreamGuard sg[2];
-    for (int s = 0; s < nset; ++s) AMT_HIP(hipStreamCreateWithFlags(&sg[s].s, hipStreamNonBlocking));
+    const double t_alloc = now();
+    StreamGuard up, comp, down;
+    AMT_HIP(hipStreamCreateWithFlags(&up.s, hipStreamNonBlocking));
+    AMT_HIP(hipStreamCreateWithFlags(&comp.s, hipStreamNonBlocking));
+    AMT_HIP(hipStreamCreateWithFlags(&down.s, hipStreamNonBlocking));
+    EventGuard uploaded[2], computed[2], drained[2];
+    for (int s = 0; s < nset; ++s) {
+        AMT_HIP(hipEventCreateWithFlags(&uploaded[s].e, hipEventDisableTiming));
+        AMT_HIP(hipEventCreateWithFlags(&computed[s].e, hipEventDisableTiming));
+        AMT_HIP(hipEventCreateWithFlags(&drained[s].e, hipEventDisableTiming));
+    }
 
-    for (int f = 0; f < 26; ++f)                              // the four 1-D arrays, once
-        if (items[f].rank == 1)
-            AMT_HIP(hipMemcpyAsync(dev[0][f], items[f].host, n1 * sizeof(T), hipMemcpyHostToDevice, sg[0].s));
-    if (nset == 2) {
-        hipEvent_t ev;
-        AMT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        AMT_HIP(hipEventRecord(ev, sg[0].s));
-        AMT_HIP(hipStreamWaitEvent(sg[1].s, ev, 0));
-        AMT_HIP(hipEventDestroy(ev));
+    for (int f = 0; f < 26; ++f) {                            // the 1-D and 2-D arrays, once
+        const Item &it = items[f];
+        if (it.rank == 1)
+            AMT_HIP(hipMemcpyAsync(dev[0][f], it.host, n1 * sizeof(T), hipMemcpyHostToDevice, up.s));
+        else if (it.rank == 2)
+            AMT_HIP(hipMemcpyAsync(dev[0][f], it.host + (size_t)(w.j_start - 1 - h.jms) * r2,
+                                   r2 * wrow * sizeof(T), hipMemcpyHostToDevice, up.s));
     }
 
     for (int c = 0; c < nchunk; ++c) {
         const int s = c % nset;
-        hipStream_t st = sg[s].s;
         const int c0 = w.j_start + (int)(c * rows);
         const int c1 = (c0 + rows - 1 < w.j_end) ? (int)(c0 + rows - 1) : w.j_end;
         const int ja = c0 - 1;                                // device row 0 <-> Fortran row ja
+        if (c >= nset) AMT_HIP(hipStreamWaitEvent(up.s, drained[s].e, 0));   // set s is free again
         for (int f = 0; f < 26; ++f) {
             const Item &it = items[f];
-            if (it.rank == 1) continue;
-            const size_t row = it.rank == 3 ? r3 : r2;
+            if (it.rank != 3 || f == F_T_AVE) continue;       // t_ave is written, never read (:210)
+            if (f == F_WW) {                                  // of ww only level 1 is an input (:161)
+                AMT_HIP(hipMemcpy2DAsync(dev[s][f] + r3 + (size_t)p.k1 * idim, r3 * sizeof(T),
+                                         it.host + (size_t)(c0 - h.jms) * r3 + (size_t)p.k1 * idim, r3 * sizeof(T),
+                                         (size_t)idim * sizeof(T), (size_t)(c1 - c0 + 1), hipMemcpyHostToDevice, up.s));
+                continue;
+            }
             const int lo = it.halo ? c0 - 1 : c0, hi = it.halo ? c1 + 1 : c1;
-            AMT_HIP(hipMemcpyAsync(dev[s][f] + (size_t)(lo - ja) * row, it.host + (size_t)(lo - h.jms) * row,
-                                   (size_t)(hi - lo + 1) * row * sizeof(T), hipMemcpyHostToDevice, st));
+            AMT_HIP(hipMemcpyAsync(dev[s][f] + (size_t)(lo - ja) * r3, it.host + (size_t)(lo - h.jms) * r3,
+                                   (size_t)(hi - lo + 1) * r3 * sizeof(T), hipMemcpyHostToDevice, up.s));
         }
+        AMT_HIP(hipEventRecord(uploaded[s].e, up.s));
         AmtArgs<T> d = h;
-        T **q = dev[s];
+        T *q[26];
+        for (int f = 0; f < 26; ++f)                          // every array as if it began at row ja
+            q[f] = items[f].rank == 2 ? dev[0][f] + (size_t)(ja - (w.j_start - 1)) * r2 : dev[s][f];
         d.ww = q[0]; d.ww_1 = q[1]; d.u = q[2]; d.u_1 = q[3]; d.v = q[4]; d.v_1 = q[5]; d.mu = q[6];
         d.mut = q[7]; d.muave = q[8]; d.muts = q[9]; d.muu = q[10]; d.muv = q[11]; d.mudf = q[12];
         d.t = q[13]; d.t_1 = q[14]; d.t_ave = q[15]; d.ft = q[16]; d.mu_tend = q[17];
         d.dnw = q[18]; d.fnm = q[19]; d.fnp = q[20]; d.rdnw = q[21]; d.msfuy = q[22];
         d.msfvx_inv = q[23]; d.msftx = q[24]; d.msfty = q[25];
         d.jms = ja; d.jme = c1 + 1; d.jts = c0; d.jte = c1;  // a tile of the same domain (global jds, jde)
-        rc = amt_device_call<T>(st, AMT_VARIANT_AUTO, d);
+        AMT_HIP(hipStreamWaitEvent(comp.s, uploaded[s].e, 0));
+        rc = amt_device_call<T>(comp.s, AMT_VARIANT_AUTO, d);
         if (rc != AMT_OK) break;
+        AMT_HIP(hipEventRecord(computed[s].e, comp.s));
+        AMT_HIP(hipStreamWaitEvent(down.s, computed[s].e, 0));
+        for (int f = 0; f < 26 && p.nk > 0; ++f) {            // the window's cells of ww, t, t_ave: nothing
+            const Item &it = items[f];                        // else of the host arrays is touched
+            if (!it.out || it.rank != 3) continue;
+            hipMemcpy3DParms cp;
+            memset(&cp, 0, sizeof cp);
+            cp.srcPtr = make_hipPitchedPtr(dev[s][f], (size_t)idim * sizeof(T), (size_t)idim, (size_t)kdim);
+            cp.dstPtr = make_hipPitchedPtr(const_cast<T *>(it.host), (size_t)idim * sizeof(T), (size_t)idim, (size_t)kdim);
+            cp.srcPos = make_hipPos((size_t)p.i0 * sizeof(T), (size_t)p.k1, 1);
+            cp.dstPos = make_hipPos((size_t)p.i0 * sizeof(T), (size_t)p.k1, (size_t)(c0 - h.jms));
+            cp.extent = make_hipExtent((size_t)(p.i1 - p.i0 + 1) * sizeof(T), (size_t)p.nk, (size_t)(c1 - c0 + 1));
+            cp.kind = hipMemcpyDeviceToHost;
+            AMT_HIP(hipMemcpy3DAsync(&cp, down.s));
+        }
+        AMT_HIP(hipEventRecord(drained[s].e, down.s));
+    }
+    if (rc == AMT_OK)                                         // the 2-D outputs, after the last kernel
         for (int f = 0; f < 26; ++f) {
             const Item &it = items[f];
-            if (!it.out) continue;
-            const size_t row = it.rank == 3 ? r3 : r2;
-            AMT_HIP(hipMemcpyAsync(const_cast<T *>(it.host) + (size_t)(c0 - h.jms) * row, dev[s][f] + row,
-                                   (size_t)(c1 - c0 + 1) * row * sizeof(T), hipMemcpyDeviceToHost, st));
+            if (!it.out || it.rank != 2) continue;
+            AMT_HIP(hipMemcpyAsync(const_cast<T *>(it.host) + (size_t)(w.j_start - h.jms) * r2, dev[0][f] + r2,
+                                   (size_t)nj * r2 * sizeof(T), hipMemcpyDeviceToHost, down.s));
         }
-    }
-    for (int s = 0; s < nset; ++s) {
-        hipError_t e = hipStreamSynchronize(sg[s].s);
+    const double t_enq = now();
+    for (hipStream_t st : {up.s, comp.s, down.s}) {
+        hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess && rc == AMT_OK)
             rc = amt_fail(AMT_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
     }
+    if (trace)
+        fprintf(stderr, "amt one-shot: %d chunk(s) of %ld rows, %s; alloc %.2f ms, enqueue %.2f ms, drain %.2f ms\n",
+                nchunk, rows, pinned ? "pinned" : "pageable", t_alloc - t_begin, t_enq - t_alloc, now() - t_enq);
     return rc;
 }
 

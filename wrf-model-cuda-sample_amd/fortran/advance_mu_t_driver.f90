@@ -141,7 +141,7 @@ program advance_mu_t_driver
 
   ! ---- the same calls with the ten 3-D arrays page-locked once (the reference driver allocates its
   !      host buffers pinned, advance_mu_t_driver.cu:97-167): the library then streams the window in
-  !      j chunks (H2D / kernel / D2H overlapped on two streams).  Timing only: the arrays have
+  !      j chunks (H2D / kernel / D2H overlapped on three streams).  Timing only: the arrays have
   !      already been advanced nsweeps times, these extra sweeps are undone by nothing and the
   !      comparison below is therefore made BEFORE them.
   nbad = 0
