@@ -109,14 +109,22 @@ int amt_advance_mu_t_f64(
     int ims, int ime, int jms, int jme, int kms, int kme,
     int its, int ite, int jts, int jte, int kts, int kte);
 
-/* Page-lock / release a host array (hipHostRegister).  When all ten 3-D arrays of a one-shot
- * call are page-locked (by these, or allocated pinned by the caller as the reference driver
- * does, advance_mu_t_driver.cu:97-167) the call streams the window in j chunks through an
- * upload, a compute and a download stream so that both directions of the host link and the
- * kernels overlap; with pageable arrays it copies synchronously in one piece like the
- * reference wrapper.  Pin once, outside the time loop. */
+/* Page-lock / release a host array (hipHostRegister).  The one-shot calls stream the window in
+ * j chunks through an upload, a compute and a download stream so that both directions of the
+ * host link and the kernels overlap.  With page-locked 3-D arrays (by these, or allocated pinned
+ * by the caller as the reference driver does, advance_mu_t_driver.cu:97-167) every copy is
+ * asynchronous; with pageable ones a second host thread issues the downloads and small arrays
+ * pass through an internal page-locked staging buffer -- about the same speed for large
+ * domains, ~2x slower than pinned for patch-sized ones.  Pin once, outside the time loop. */
 int amt_host_pin(void *ptr, size_t bytes);
 int amt_host_unpin(void *ptr);
+
+/* The one-shot calls keep their device workspace (three streams, six events, the buffer arena
+ * when it is at most 1 GiB) per calling host thread between calls, instead of the reference
+ * wrapper's allocate-and-free on every call (advance_mu_t_no_async.cu:178-244,392-423), which
+ * at WRF patch sizes costs more than the call itself.  This frees the calling thread's
+ * workspace now; it is freed anyway when the thread ends. */
+int amt_host_release(void);
 
 /* ------------------------------------------------------------------------
  * (2) Device-resident drop-ins: the same call with every array pointer in

@@ -31,7 +31,10 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--rows", type=int, nargs="*", default=[0])
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--no-thread", action="store_true", help="pageable arrays: no download thread (one piece)")
     a = ap.parse_args()
+    if a.no_thread:
+        os.environ["AMT_STREAM_THREAD"] = "0"
     import torch
     import __graft_entry__ as g
     pkg = g.load_package()

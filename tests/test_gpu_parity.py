@@ -80,11 +80,17 @@ def test_one_shot_host_call_matches_oracle(pkg, oracle, shape, flag, dtype):
     assert_patch_equal(pkg, p, want, f"one-shot {shape}/{flag}")
 
 
-@pytest.mark.parametrize("rows", [1, 5, 13])
-def test_streamed_one_shot_chunks_match_oracle(pkg, oracle, monkeypatch, rows):
+@pytest.mark.parametrize("mode", ["default", "no-pack", "no-thread", "plain"])
+@pytest.mark.parametrize("rows", [1, 5, 13, 1000])
+def test_streamed_one_shot_chunks_match_oracle(pkg, oracle, monkeypatch, rows, mode):
     """The one-shot drop-in streams the window in j chunks (upload, compute and download streams,
-    two device buffer sets); any chunking must give the oracle's bits."""
+    two device buffer sets; pageable arrays: a download thread, small arrays packed through a
+    staging buffer); any chunking and any of the regimes must give the oracle's bits."""
     monkeypatch.setenv("AMT_STREAM_ROWS", str(rows))
+    if mode in ("no-pack", "plain"):
+        monkeypatch.setenv("AMT_STREAM_PACK", "0")
+    if mode in ("no-thread", "plain"):
+        monkeypatch.setenv("AMT_STREAM_THREAD", "0")
     for flag in ("none", "specified"):
         p = cases.make_case(pkg, "64x40x64", flag, np.float64)
         want = p.copy()

@@ -36,7 +36,7 @@ program advance_mu_t_driver
   integer(c_int) :: rc
   type(c_ptr) :: dom
   real(c_float) :: ms
-  integer(kind=8) :: c0, c1, hz
+  integer(kind=8) :: c0, c1, cmid, hz
   real(kind=8) :: cells, secs
   integer :: nbad
 
@@ -132,12 +132,18 @@ program advance_mu_t_driver
                          ids, ide, jds, jde, kde,             &
                          ims, ime, jms, jme, kms, kme,        &
                          its, ite, jts, jte, kts, kte )
+      if (s == 1) call system_clock(count=cmid)
     end do
   end block
   call system_clock(count=c1)
-  secs = real(c1 - c0, 8) / real(hz, 8)
-  print '(a,i0,a,f10.4,a,f12.1,a)', 'one-shot host path:   ', nsweeps, ' calls,  ', secs * 1.0d3 / nsweeps, &
-        ' ms/call  (alloc+H2D+kernel+D2H), ', cells * nsweeps / secs / 1.0d6, ' Mcells/s'
+  ! the first call creates this thread's device workspace (streams, events, arena), which later calls reuse
+  secs = real(cmid - c0, 8) / real(hz, 8)
+  print '(a,f10.4,a)', 'one-shot host path:   first call ', secs * 1.0d3, ' ms (creates the device workspace)'
+  if (nsweeps > 1) then
+     secs = real(c1 - cmid, 8) / real(hz, 8)
+     print '(a,i0,a,f10.4,a,f12.1,a)', 'one-shot host path:   ', nsweeps - 1, ' calls,  ', secs * 1.0d3 / (nsweeps - 1), &
+           ' ms/call  (H2D+kernel+D2H), ', cells * (nsweeps - 1) / secs / 1.0d6, ' Mcells/s'
+  end if
 
   ! ---- the same calls with the ten 3-D arrays page-locked once (the reference driver allocates its
   !      host buffers pinned, advance_mu_t_driver.cu:97-167): the library then streams the window in

@@ -55,6 +55,11 @@ MODULE amt_c_binding
          type(c_ptr), value :: ptr
          integer(c_int) :: rc
       end function
+      ! free the device workspace the one-shot calls of this thread keep between calls
+      function amt_host_release() bind(C, name="amt_host_release") result(rc)
+         import :: c_int
+         integer(c_int) :: rc
+      end function
 
       ! error text of the calling thread (NUL-terminated C string)
       function amt_last_error() bind(C, name="amt_last_error") result(msg)

@@ -69,6 +69,7 @@ SYMBOLS = {
     "amt_calib_stream_copy": (_I, [_P, _P, _P, ctypes.c_size_t, _I]),
     "amt_host_pin": (_I, [_P, ctypes.c_size_t]),
     "amt_host_unpin": (_I, [_P]),
+    "amt_host_release": (_I, []),
 }
 
 
