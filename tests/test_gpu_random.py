@@ -25,6 +25,12 @@ def random_case(pkg, rng):
     jme = jde + int(rng.integers(0, 4))
     kms = int(rng.choice([1, 1, 0, -2]))
     kme = kde + int(rng.integers(0, 3))
+    if rng.random() < 0.4:
+        # rows a multiple of 16 bytes and a level count the LDS-DMA flavour of the march kernel takes
+        # (KPT | nk): that flavour, not the plain one, then runs these cases
+        nk = int(rng.choice([4, 8, 12, 16, 20, 24, 40, 60]))
+        kde, kme = nk + 1, nk + 1 + int(rng.integers(0, 3))
+        ime += (-(ime - ims + 1)) % 4
     # tile: the whole domain, or a random sub-tile (as an OpenMP tile / slab would be)
     its, ite, jts, jte = 1, ide, 1, jde
     if rng.random() < 0.5:
