@@ -51,6 +51,16 @@ static int amt_env_int(const char *name, int dflt)
 #ifndef AMT_NT_STORE
 #define AMT_NT_STORE 0
 #endif
+// Cache policy of the streams, measured in one process on the same arrays (profiles/ab_libs.py,
+// 4096x60x4096 fp64, +-0.01 ms): nt loads of t, ft, ww_1 (each read exactly once) 16.28 -> 16.06 ms,
+// every one of the three contributes; nt also on u, u_1 (each line is read by two overlapping
+// loads) +0.4 ms; nt on the LDS-DMA loads +0.3 ms; nt stores +0.1 ms.
+#ifndef AMT_NT_LOAD
+#define AMT_NT_LOAD 1   /* 1: t, ft, ww_1 with the nt policy; 2: u, u_1 too */
+#endif
+#ifndef AMT_NT_DMA
+#define AMT_NT_DMA 0    /* cache-policy bits of the bulk LDS-DMA loads (2 = nt) */
+#endif
 #ifndef AMT_COL_PRIO
 #define AMT_COL_PRIO 0
 #endif
@@ -79,6 +89,16 @@ template <typename T>
 __device__ __forceinline__ void amt_st(T *ubase, unsigned voff, T x)
 {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(ubase) + voff) = x;
+}
+// once-read inputs (level = which AMT_NT_LOAD setting turns the nt policy on for this stream)
+template <int LEVEL, typename T>
+__device__ __forceinline__ T amt_ld_stream(const T *ubase, unsigned voff)
+{
+#if AMT_NT_LOAD
+    if (AMT_NT_LOAD >= LEVEL)
+        return __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(ubase) + voff));
+#endif
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(ubase) + voff);
 }
 // streaming store: the three 3-D outputs are written once and not read again in the sweep
 template <typename T>
@@ -404,9 +424,9 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 for (int m = 0; m < KPT; ++m) {
                     if (FULL || m < nlev) {
                         const unsigned om = o3 + (unsigned)m * lev;
-                        told[m] = amt_ld(t_b, om);
-                        ftk[m] = amt_ld(ft_b, om);
-                        w1[m] = amt_ld(ww1_b, om);
+                        told[m] = amt_ld_stream<1>(t_b, om);
+                        ftk[m] = amt_ld_stream<1>(ft_b, om);
+                        w1[m] = amt_ld_stream<1>(ww1_b, om);
                     }
                 }
             }
@@ -671,7 +691,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 if (dok)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
                                                      (__attribute__((address_space(3))) void *)(lds + (size_t)(kf + q * LPI) * 64),
-                                                     16, 0, 0);
+                                                     16, 0, AMT_NT_DMA);
             }
         };
         // i halo of a t_1 row: per level the elements left of lane 0 and right of lane 63, DMA'd one
@@ -773,12 +793,12 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                         uu = U[K * 64 + lane];
                         const T up_in = U[K * 64 + lr];
                         uup = lane == 63 ? UH[K] : up_in;
-                    } else { uu = amt_ld(u_b, om); uup = amt_ld(u_b + 1, om); }
+                    } else { uu = amt_ld_stream<2>(u_b, om); uup = amt_ld_stream<2>(u_b + 1, om); }
                     if (XD >= 3) {
                         u1 = U1[K * 64 + lane];
                         const T up_in = U1[K * 64 + lr];
                         u1p = lane == 63 ? UH[nk + K] : up_in;
-                    } else { u1 = amt_ld(u1_b, om); u1p = amt_ld(u1_b + 1, om); }
+                    } else { u1 = amt_ld_stream<2>(u1_b, om); u1p = amt_ld_stream<2>(u1_b + 1, om); }
                     const T vn = V[K * 64 + lane], t1n = T1n[K * 64 + lane];
                     const T t1c = T1c[K * 64 + lane];
                     const T t1l_in = T1c[K * 64 + ll], t1r_in = T1c[K * 64 + lr];
@@ -808,9 +828,9 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
                     const unsigned om = o3 + (unsigned)m * lev;
-                    told[m] = amt_ld(t_b, om);
-                    ftk[m] = amt_ld(ft_b, om);
-                    w1[m] = amt_ld(ww1_b, om);
+                    told[m] = amt_ld_stream<1>(t_b, om);
+                    ftk[m] = amt_ld_stream<1>(ft_b, om);
+                    w1[m] = amt_ld_stream<1>(ww1_b, om);
                 }
             }
             amt_lds_barrier();                                       // 2: DM published (DMA keeps flying)
