@@ -1011,13 +1011,15 @@ template <typename T, int KPT>
 static hipError_t amt_march_launch_dma(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g)
 {
     if constexpr (KPT % (64 / (64 / (16 / (int)sizeof(T)))) == 0) {
-        // as many inputs through the DMA as LDS allows -- where measured to pay: all of them in fp32
-        // (4096x60x4096: 8.4 vs 9.3 ms), v_1 only in fp64 (the u/u_1 reads from LDS cost ~10 more live
-        // VGPRs and spill: nk 40: 11.3 vs 12.5 ms) and whenever u fits but u_1 does not (XD 2 never won)
+        // more inputs through the DMA where measured to pay (in-process A/B, profiles/ab_libs.py):
+        // fp32: all of them (4096x60x4096: 8.27 vs 8.75 ms; NK 80: 11.4 vs 13.2 ms), never u without
+        // u_1 (XD 2 is the slowest everywhere); fp64: at KPT 4 the u/u_1 reads from LDS cost ~10 more
+        // live VGPRs and spill (NK 40: 11.86 vs 11.26 ms; NK 60: v_1 alone 15.77 vs 15.72 without), at
+        // KPT 2 (NK <= 30) they fit and pay (NK 20: 5.62 vs 5.82 ms)
         int xd = 3;
         while (xd > 0 && amt_march_dma_lds<T>(p.nk, xd) > 160 * 1024) --xd;
-        if (sizeof(T) == 8 && xd > 1) xd = 1;
         if (xd == 2) xd = 1;
+        if (sizeof(T) == 8 && !(xd == 3 && KPT <= 2)) xd = 0;
         const int cap = amt_env_int("AMT_MARCH_XD", -1);
         if (cap >= 0) {
             xd = cap > 3 ? 3 : cap;
