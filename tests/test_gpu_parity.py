@@ -408,37 +408,49 @@ def test_full_size_slab_properties(pkg, oracle, torch_mod):
             assert bits_equal(got, want.arrays[n][1:4]), (jlo, n)
 
 
-def test_large_domain_checksums_agree_across_kernels(pkg, oracle, torch_mod):
-    """Every cell of a 4096 x 60 x 1024 fp64 domain (a quarter of BASELINE.json configs[2], 21 GB):
+@pytest.mark.parametrize("dims,dtype", [((4096, 60, 1024), np.float64), ((4096, 60, 4096), np.float64),
+                                        ((8192, 80, 2048), np.float32)],
+                         ids=["quarter-f64", "configs2-4096x60x4096-f64", "configs4-quarter-8192x80-f32"])
+def test_large_domain_checksums_agree_across_kernels(pkg, oracle, torch_mod, dims, dtype):
+    """Every cell of a large domain -- a quarter of BASELINE.json configs[2] (21 GB), configs[2]
+    itself (4096 x 60 x 4096 fp64, 82 GB resident) and a quarter of configs[4] (8192 x 80 fp32):
     the production kernel in one launch, the same kernel swept as seven ragged j tiles (other block
-    sizes, other prologues) and the simple column kernel must leave bit-identical outputs -- compared through wrap-around
-    integer checksums of the raw bit patterns -- and a few slabs are anchored to the oracle."""
+    sizes, other prologues) and the simple column kernel must leave bit-identical outputs -- compared
+    through wrap-around integer checksums of the raw bit patterns -- and a few slabs are anchored to
+    the oracle."""
     import torch
     S = pkg.synth
-    dims = (4096, 60, 1024)
     b = S.domain_bounds(*dims, aligned=True)
+    need = 10 * b.idim * b.kdim * b.jdim * np.dtype(dtype).itemsize * 1.1
+    if torch.cuda.mem_get_info(0)[0] < need:
+        pytest.skip(f"needs {need / 1e9:.0f} GB of free HBM")
+    ibits = torch.int64 if dtype == np.float64 else torch.int32
 
     def run(variant, tiles):
-        dev = S.make_patch(b, pkg.GridConfig(specified=True), seed=77, device="cuda:0")
+        dev = S.make_patch(b, pkg.GridConfig(specified=True), dtype=dtype, seed=77, device="cuda:0")
         edges = np.linspace(1, dims[2] + 1, tiles + 1).astype(int)
         for a, c in zip(edges[:-1], edges[1:]):
             pkg.advance_mu_t(*dev.with_bounds(jts=int(a), jte=int(c) - 1 + (c == edges[-1])).args(), variant=variant)
         torch.cuda.synchronize()
-        sums = {n: int(dev.arrays[n].view(torch.int64).sum().item()) for n in S.OUTPUTS}
+        sums = {n: int(dev.arrays[n].view(ibits).sum(dtype=torch.int64).item()) for n in S.OUTPUTS}
         return dev, sums
 
     dev, auto = run(pkg.VARIANT_AUTO, 1)
     # anchor: three slabs against the oracle
-    for jlo in (2, 511, 1021):
+    for jlo in (2, dims[2] // 2 - 1, dims[2] - 3):
         sb = b.replace(jms=jlo - 1, jme=jlo + 3, jts=jlo, jte=jlo + 2)
-        want = S.make_patch(sb, pkg.GridConfig(specified=True), seed=77, global_dims=dims)
+        want = S.make_patch(sb, pkg.GridConfig(specified=True), dtype=dtype, seed=77, global_dims=dims)
         oracle.advance_mu_t_omp(*want.args(), nthreads=3)
         for n in S.OUTPUTS:
             got = dev.arrays[n][jlo - b.jms: jlo + 3 - b.jms].cpu().numpy()
             assert bits_equal(got, want.arrays[n][1:4]), (jlo, n)
     del dev
     torch.cuda.empty_cache()
-    _, tiled = run(pkg.VARIANT_MARCH, 7)          # ragged j tiles: other block sizes, other prologues
+    dev, tiled = run(pkg.VARIANT_MARCH, 7)        # ragged j tiles: other block sizes, other prologues
     assert tiled == auto
-    _, column = run(pkg.VARIANT_COLUMN, 1)
+    del dev
+    torch.cuda.empty_cache()
+    dev, column = run(pkg.VARIANT_COLUMN, 1)
     assert column == auto
+    del dev
+    torch.cuda.empty_cache()
