@@ -51,7 +51,8 @@ typedef enum amt_status {
     AMT_ERR_PRECONDITION = 2,  /* bounds violate the preconditions above            */
     AMT_ERR_INVALID_ARG = 3,   /* null pointer, bad dtype / field id / variant      */
     AMT_ERR_NO_DEVICE = 4,     /* no gfx950 device visible                          */
-    AMT_ERR_ALLOC = 5          /* device or host allocation failed                  */
+    AMT_ERR_ALLOC = 5,         /* device or host allocation failed                  */
+    AMT_ERR_COMM = 6           /* RCCL could not be loaded or a collective call failed */
 } amt_status;
 
 /* Kernel variants (amt_set_variant / `variant` arguments).  AMT_VARIANT_AUTO picks
@@ -228,7 +229,42 @@ int amt_synth_fill_device(void *hip_stream, int field, int dtype_bytes, void *ds
                           long gidim, long gkdim, long gjdim);
 
 /* ------------------------------------------------------------------------
- * (5) Profiling aid: a plain streaming copy of nbytes (device to device) that moves
+ * (5) j-slabs over several GPUs, one process per GPU: each rank owns rows jts..jte of the
+ *     domain in a resident handle whose memory holds exactly one more row on either side
+ *     (GLOBAL ids..jde, LOCAL jms = jts-1, jme = jte+1), as a WRF patch does.  Before a
+ *     boundary row is computed the rank receives from the rank above row jte+1 of v, v_1, t_1,
+ *     muv, msfvx_inv (module_small_step_em.f90:143-144,241) and from the rank below row jts-1
+ *     of t_1 (:242): RCCL send/recv in one group on a communication stream, on which the two
+ *     boundary rows then run, while the interior rows compute on the domain's stream.  Outputs
+ *     need no exchange.  The reference splits j over its GPUs inside one process and refills
+ *     the halos from the host on every call (advance_mu_t_no_async.cu:108-162).
+ *     RCCL is loaded on first use (dlopen; AMT_RCCL_LIBRARY overrides the name).
+ * ------------------------------------------------------------------------ */
+#define AMT_UNIQUE_ID_BYTES 128              /* sizeof(ncclUniqueId) */
+enum amt_slab_flags {
+    AMT_SLAB_NO_OVERLAP = 1,                 /* exchange, then all rows, on one stream          */
+    AMT_SLAB_LOOPBACK = 2                    /* one-rank test mode: both neighbours are this rank */
+};
+typedef struct amt_slab amt_slab;
+
+int amt_set_device(int device);              /* hipSetDevice for hosts without a HIP binding     */
+/* rank 0: a fresh communicator id (ncclGetUniqueId) to hand to every rank */
+int amt_comm_unique_id(void *id_out /* AMT_UNIQUE_ID_BYTES */);
+/* the same through a file for hosts without MPI: rank 0 creates and publishes the id as
+ * `path`, the others wait up to timeout_s for it; every rank gets the id in id_out */
+int amt_comm_rendezvous_file(const char *path, int rank, double timeout_s, void *id_out);
+/* collective over the `world` ranks (ncclCommInitRank); the domain must outlive the slab */
+int amt_slab_create(amt_slab **out, amt_domain *domain, int rank, int world,
+                    const void *unique_id, int flags);
+int amt_slab_destroy(amt_slab *slab);
+int amt_slab_exchange(amt_slab *slab);       /* the halo exchange alone                           */
+int amt_slab_step(amt_slab *slab, int n_sweeps);             /* asynchronous                      */
+int amt_slab_step_timed(amt_slab *slab, int n_sweeps, float *ms_total);
+int amt_slab_sync(amt_slab *slab);
+long amt_slab_halo_bytes(const amt_slab *slab);              /* sent (= received) per sweep      */
+
+/* ------------------------------------------------------------------------
+ * (6) Profiling aid: a plain streaming copy of nbytes (device to device) that moves
  *     bytes_per_lane = 4, 8 or 16 bytes per lane per access -- a KNOWN byte count in
  *     the kernels' own access width, used to calibrate rocprofv3's FETCH_SIZE /
  *     WRITE_SIZE on gfx950 (profiles/README.md).

@@ -5,6 +5,7 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before the HIP library initialises: both must share one HIP runtime (lib.py)
 
 import cases
 from conftest import bits_equal
@@ -56,3 +57,34 @@ def test_driver_outputs_match_oracle(pkg, oracle, drivers, tmp_path, itemsize, i
     for n in pkg.synth.OUTPUTS:
         got = np.fromfile(tmp_path / f"{n}.bin", dtype=dtype).reshape(want.arrays[n].shape)
         assert bits_equal(got, want.arrays[n]), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("itemsize", [8, 4])
+def test_slab_driver_loopback_agrees_with_the_torch_path(pkg, drivers, tmp_path, itemsize):
+    """The one-process-per-GPU Fortran host (advance_mu_t_slab_driver) in its one-rank loopback
+    mode: RCCL communicator, halo exchange with itself, boundary rows on the communication stream.
+    sum(mu) over the slab after warm-up + timed sweeps must equal the torch path's with the halo
+    rows copied by hand."""
+    import re
+    exe = FDIR / ("advance_mu_t_slab_driver_f64" if itemsize == 8 else "advance_mu_t_slab_driver_f32")
+    ni, nk, nj, sweeps = 200, 12, 20, 3
+    env = dict(__import__("os").environ, AMT_RENDEZVOUS_FILE=str(tmp_path / "uid"), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([str(exe), str(ni), str(nk), str(nj), str(sweeps), "1"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"halo bytes/sweep (\d+); sum\(mu\)\s+([-+0-9.Ee]+)", r.stdout)
+    assert m and int(m.group(1)) > 0, r.stdout
+    dtype = np.float64 if itemsize == 8 else np.float32
+    S = pkg.synth
+    b = S.domain_bounds(ni, nk, nj, aligned=True)
+    want = S.make_patch(b, pkg.GridConfig(), dtype=dtype, seed=12345, device="cuda:0")
+    a = want.arrays
+    for n in S.HALO_FROM_ABOVE:
+        a[n][-1].copy_(a[n][1])
+    a["t_1"][0].copy_(a["t_1"][-2])
+    for _ in range(2 + sweeps):                                   # the driver warms up with two sweeps
+        pkg.advance_mu_t(*want.args())
+    torch.cuda.synchronize()
+    mu = want.to_host().arrays["mu"]
+    total = mu[1:-1, 1 - b.ims:1 - b.ims + ni].astype(np.float64).sum()
+    assert abs(float(m.group(2)) - total) <= 1e-9 * abs(total), (m.group(2), total)

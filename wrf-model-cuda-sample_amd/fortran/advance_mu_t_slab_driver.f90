@@ -1,0 +1,130 @@
+! advance_mu_t_slab_driver.f90 -- Fortran-90 host of the j-decomposed run: one process per GPU.
+!
+! Every rank owns the rows jlo..jhi of the NI x NK x NJ domain as a resident device patch
+! (GLOBAL ids..jde, LOCAL jms = jlo-1, jme = jhi+1 -- the triple WRF itself passes), filled from
+! the seeded index-based generator of include/amt_synth.h, and calls amt_slab_step: the one-row
+! input halos travel as RCCL send/recv on a communication stream together with the two boundary
+! rows while the interior rows compute (include/amt_advance_mu_t.h section 5).  The reference
+! splits j over its GPUs inside one process and refills the halos from the host on every call
+! (advance_mu_t_no_async.cu:108-162).
+!
+!   RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT come from the launcher, e.g.
+!     python -m torch.distributed.run --no-python --nnodes=1 --nproc-per-node 8 \
+!         --master-addr 127.0.0.1 --master-port 29533 ./advance_mu_t_slab_driver_f64 4096 60 4096 20
+!   (or mpirun with the same variables exported).  Without them: one rank, no communicator.
+!   AMT_RENDEZVOUS_FILE overrides the file through which rank 0 hands out the communicator id.
+!
+!   advance_mu_t_slab_driver [NI NK NJ [nsweeps [loopback]]]
+!     loopback = 1: one-rank self test, the rank is its own neighbour (exercises RCCL and the
+!     two-stream schedule on a single GPU)
+program advance_mu_t_slab_driver
+  use iso_c_binding
+  use amt_c_binding
+  implicit none
+
+  integer, parameter :: wp = kind(1.0)          ! default REAL: fp32, or fp64 with -fdefault-real-8
+  integer :: ni, nk, nj, nsweeps, loopback, rank, world, local_rank, nrows, jlo, jhi
+  integer :: ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte
+  integer :: idim, flags
+  character(len=256) :: arg
+  character(len=512) :: path, port
+  character(kind=c_char), target :: uid(128)
+  character(kind=c_char), allocatable :: cpath(:)
+  integer(c_int64_t), parameter :: seed = 12345_c_int64_t
+  type(c_ptr) :: dom, slab, idptr
+  real(c_float) :: ms
+  real(wp), allocatable, target :: mu(:,:)
+  real(kind=8) :: cells, bytes
+  integer :: n
+
+  ni = 512; nk = 60; nj = 512; nsweeps = 20; loopback = 0
+  if (command_argument_count() >= 3) then
+     call get_command_argument(1, arg); read (arg, *) ni
+     call get_command_argument(2, arg); read (arg, *) nk
+     call get_command_argument(3, arg); read (arg, *) nj
+  end if
+  if (command_argument_count() >= 4) then
+     call get_command_argument(4, arg); read (arg, *) nsweeps
+  end if
+  if (command_argument_count() >= 5) then
+     call get_command_argument(5, arg); read (arg, *) loopback
+  end if
+  rank = env_int('RANK', 0)
+  world = env_int('WORLD_SIZE', 1)
+  local_rank = env_int('LOCAL_RANK', rank)
+  if (nj < world) error stop 'fewer rows than ranks'
+  call amt_check(amt_set_device(int(local_rank, c_int)), 'amt_set_device')
+
+  ! the domain (SURVEY.md section 8 convention), i memory padded to whole 32-element runs ...
+  ids = 1; ide = ni + 1; jds = 1; jde = nj + 1; kde = nk + 1
+  ims = 1 - 32
+  idim = ((ni + 1 - ims + 1 + 31) / 32) * 32
+  ime = ims + idim - 1
+  kms = 1; kme = nk + 1; kts = 1; kte = kde; its = 1; ite = ide
+  ! ... and this rank's rows of it: one halo row each side in memory
+  nrows = jde - jds
+  jlo = jds + (nrows * rank) / world
+  jhi = jds + (nrows * (rank + 1)) / world - 1
+  jms = jlo - 1; jme = jhi + 1; jts = jlo; jte = jhi
+
+  call amt_check(amt_domain_create(dom, int(storage_size(1.0_wp)/8, c_int), 0_c_int, 0_c_int, 0_c_int,  &
+                                   ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme,            &
+                                   its, ite, jts, jte, kts, kte), 'amt_domain_create')
+  call amt_check(amt_domain_fill_synthetic(dom, seed, int(ims, c_long), int(kms - 1, c_long), int(jms, c_long), &
+                                           int(ni + 2, c_long), int(nk + 1, c_long), int(nj + 2, c_long)), &
+                 'amt_domain_fill_synthetic')
+
+  flags = 0
+  idptr = c_null_ptr
+  if (world > 1 .or. loopback /= 0) then
+     call get_environment_variable('AMT_RENDEZVOUS_FILE', path)
+     if (len_trim(path) == 0) then
+        call get_environment_variable('MASTER_PORT', port)
+        if (len_trim(port) == 0) port = '0'
+        path = '/tmp/amt_uid_' // trim(port)
+     end if
+     allocate (cpath(len_trim(path) + 1))
+     do n = 1, len_trim(path)
+        cpath(n) = path(n:n)
+     end do
+     cpath(len_trim(path) + 1) = c_null_char
+     call amt_check(amt_comm_rendezvous_file(cpath, int(rank, c_int), 120.0_c_double, uid), 'amt_comm_rendezvous_file')
+     idptr = c_loc(uid)
+     if (loopback /= 0) flags = 2                      ! AMT_SLAB_LOOPBACK
+  end if
+  call amt_check(amt_slab_create(slab, dom, int(rank, c_int), int(world, c_int), idptr, int(flags, c_int)), 'amt_slab_create')
+
+  call amt_check(amt_slab_step(slab, 2_c_int), 'amt_slab_step (warm-up)')   ! code objects, RCCL connections
+  call amt_check(amt_slab_sync(slab), 'amt_slab_sync')
+  call amt_check(amt_slab_step_timed(slab, int(nsweeps, c_int), ms), 'amt_slab_step_timed')
+  call amt_check(amt_slab_sync(slab), 'amt_slab_sync')
+
+  cells = real(ni, 8) * real(nk, 8) * real(jhi - jlo + 1, 8)
+  bytes = real(storage_size(1.0_wp)/8, 8) * real(ni, 8) * real(jhi - jlo + 1, 8) * (11.0d0 * nk + 14.0d0)
+  allocate (mu(ims:ime, jms:jme))
+  call amt_check(amt_domain_download(dom, AMT_F_MU, c_loc(mu)), 'amt_domain_download')
+  print '(a,i0,a,i0,a,i0,a,i0,a,i0,a,i0,a,f9.4,a,f11.1,a,f8.1,a,i0,a,es22.14)',                       &
+        'rank ', rank, '/', world, ': rows ', jlo, '..', jhi, ' of ', ni, 'x', nk, ' real*x  ',       &
+        ms / nsweeps, ' ms/sweep ', cells * nsweeps / (ms * 1.0d-3) / 1.0d6, ' Mcells/s ',            &
+        bytes * nsweeps / (ms * 1.0d-3) / 1.0d9, ' GB/s algorithmic; halo bytes/sweep ',              &
+        amt_slab_halo_bytes(slab), '; sum(mu) ', sum(real(mu(1:ni, jlo:jhi), 8))
+
+  call amt_check(amt_slab_destroy(slab), 'amt_slab_destroy')
+  call amt_check(amt_domain_destroy(dom), 'amt_domain_destroy')
+
+contains
+
+  integer function env_int(name, dflt) result(v)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: dflt
+    character(len=64) :: s
+    integer :: ios
+    call get_environment_variable(name, s)
+    v = dflt
+    if (len_trim(s) > 0) then
+       read (s, *, iostat=ios) v
+       if (ios /= 0) v = dflt
+    end if
+  end function env_int
+
+end program advance_mu_t_slab_driver

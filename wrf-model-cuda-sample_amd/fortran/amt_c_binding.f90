@@ -124,6 +124,65 @@ MODULE amt_c_binding
          integer(c_int) :: rc
       end function
 
+      function amt_domain_fill_synthetic(handle, seed, gi0, gk0, gj0, gidim, gkdim, gjdim)        &
+            bind(C, name="amt_domain_fill_synthetic") result(rc)
+         import :: c_ptr, c_int, c_int64_t, c_long
+         type(c_ptr), value :: handle
+         integer(c_int64_t), value :: seed
+         integer(c_long), value :: gi0, gk0, gj0, gidim, gkdim, gjdim
+         integer(c_int) :: rc
+      end function
+
+      ! ---- j-slabs over several GPUs, one process per GPU (RCCL halos) ----
+      function amt_set_device(device) bind(C, name="amt_set_device") result(rc)
+         import :: c_int
+         integer(c_int), value :: device
+         integer(c_int) :: rc
+      end function
+      function amt_comm_rendezvous_file(path, rank, timeout_s, id_out) bind(C, name="amt_comm_rendezvous_file") result(rc)
+         import :: c_char, c_int, c_double
+         character(kind=c_char), intent(in) :: path(*)      ! NUL-terminated
+         integer(c_int), value :: rank
+         real(c_double), value :: timeout_s
+         character(kind=c_char), intent(out) :: id_out(128)
+         integer(c_int) :: rc
+      end function
+      function amt_slab_create(slab, domain, rank, world, unique_id, flags) bind(C, name="amt_slab_create") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr) :: slab                         ! amt_slab **
+         type(c_ptr), value :: domain, unique_id     ! unique_id may be c_null_ptr when world == 1
+         integer(c_int), value :: rank, world, flags
+         integer(c_int) :: rc
+      end function
+      function amt_slab_destroy(slab) bind(C, name="amt_slab_destroy") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: slab
+         integer(c_int) :: rc
+      end function
+      function amt_slab_step(slab, n_sweeps) bind(C, name="amt_slab_step") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: slab
+         integer(c_int), value :: n_sweeps
+         integer(c_int) :: rc
+      end function
+      function amt_slab_step_timed(slab, n_sweeps, ms_total) bind(C, name="amt_slab_step_timed") result(rc)
+         import :: c_ptr, c_int, c_float
+         type(c_ptr), value :: slab
+         integer(c_int), value :: n_sweeps
+         real(c_float) :: ms_total
+         integer(c_int) :: rc
+      end function
+      function amt_slab_sync(slab) bind(C, name="amt_slab_sync") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: slab
+         integer(c_int) :: rc
+      end function
+      function amt_slab_halo_bytes(slab) bind(C, name="amt_slab_halo_bytes") result(n)
+         import :: c_ptr, c_long
+         type(c_ptr), value :: slab
+         integer(c_long) :: n
+      end function
+
       ! (4) synthetic inputs
       function amt_synth_fill_host(field, dtype_bytes, dst, seed, idim, kdim, jdim, gi0, gk0, gj0, &
                                    gidim, gkdim, gjdim) bind(C, name="amt_synth_fill_host") result(rc)

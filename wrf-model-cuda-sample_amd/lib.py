@@ -13,7 +13,7 @@ PKG_DIR = Path(__file__).resolve().parent
 _LIB_NAME = "libamt_advance_mu_t.so"
 
 # status codes of include/amt_advance_mu_t.h
-OK, ERR_HIP, ERR_PRECONDITION, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_ALLOC = range(6)
+OK, ERR_HIP, ERR_PRECONDITION, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_ALLOC, ERR_COMM = range(7)
 
 
 class AmtError(RuntimeError):
@@ -70,6 +70,16 @@ SYMBOLS = {
     "amt_host_pin": (_I, [_P, ctypes.c_size_t]),
     "amt_host_unpin": (_I, [_P]),
     "amt_host_release": (_I, []),
+    "amt_set_device": (_I, [_I]),
+    "amt_comm_unique_id": (_I, [_P]),
+    "amt_comm_rendezvous_file": (_I, [ctypes.c_char_p, _I, ctypes.c_double, _P]),
+    "amt_slab_create": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P, _I]),
+    "amt_slab_destroy": (_I, [_P]),
+    "amt_slab_exchange": (_I, [_P]),
+    "amt_slab_step": (_I, [_P, _I]),
+    "amt_slab_step_timed": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
+    "amt_slab_sync": (_I, [_P]),
+    "amt_slab_halo_bytes": (_L, [_P]),
 }
 
 
