@@ -17,7 +17,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/syscall.h>
+#include <time.h>
 #include <unistd.h>
 #include <string>
 #include <vector>
@@ -1051,11 +1053,15 @@ extern "C" int amt_comm_unique_id(void *id_out)
 }
 
 // Rendezvous for hosts without MPI: rank 0 creates the id and publishes it as `path` (written
-// under a temporary name, then renamed), the other ranks wait for the file.
+// under a temporary name, then renamed), the other ranks wait for the file.  A file left by an
+// earlier launch must not be taken for this one's: rank 0 removes it first, and the others ignore
+// files last written more than a minute before they started waiting (use a fresh path per launch,
+// e.g. derived from the launcher's port, when relaunching faster than that).
 extern "C" int amt_comm_rendezvous_file(const char *path, int rank, double timeout_s, void *id_out)
 {
     if (!path || !*path || !id_out || rank < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad rendezvous argument");
     if (rank == 0) {
+        (void)unlink(path);
         int rc = amt_comm_unique_id(id_out);
         if (rc) return rc;
         const std::string tmp = std::string(path) + ".tmp";
@@ -1067,12 +1073,16 @@ extern "C" int amt_comm_rendezvous_file(const char *path, int rank, double timeo
             return amt_fail(AMT_ERR_COMM, "cannot publish %s", path);
         return AMT_OK;
     }
+    const time_t entered = time(nullptr);
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
-        if (FILE *f = fopen(path, "rb")) {
-            const size_t n = fread(id_out, 1, AMT_UNIQUE_ID_BYTES, f);
-            fclose(f);
-            if (n == AMT_UNIQUE_ID_BYTES) return AMT_OK;
+        struct stat st;
+        if (stat(path, &st) == 0 && st.st_mtime >= entered - 60) {
+            if (FILE *f = fopen(path, "rb")) {
+                const size_t n = fread(id_out, 1, AMT_UNIQUE_ID_BYTES, f);
+                fclose(f);
+                if (n == AMT_UNIQUE_ID_BYTES) return AMT_OK;
+            }
         }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
             return amt_fail(AMT_ERR_COMM, "no rendezvous file %s after %.0f s", path, timeout_s);
