@@ -1,0 +1,152 @@
+// amt_domain.hip -- the resident domain handle amt_domain_*: native owner of the 26 device arrays,
+// a stream and the scalars, for C / Fortran hosts that keep the state on the GPU across sub-steps.
+#include "amt_internal.h"
+
+extern "C" int amt_domain_destroy(amt_domain *d)
+{
+    if (!d) return AMT_OK;
+    DeviceScope scope(d->device);
+    for (void *&q : d->field)
+        if (q) { (void)hipFree(q); q = nullptr; }
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_create(amt_domain **out, int dtype_bytes,
+                                 int periodic_x, int specified, int nested,
+                                 int ids, int ide, int jds, int jde, int kde,
+                                 int ims, int ime, int jms, int jme, int kms, int kme,
+                                 int its, int ite, int jts, int jte, int kts, int kte)
+{
+    if (!out) return amt_fail(AMT_ERR_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    if (dtype_bytes != 4 && dtype_bytes != 8) return amt_fail(AMT_ERR_INVALID_ARG, "dtype_bytes must be 4 or 8");
+    if (ime < ims || jme < jms || kme < kms) return amt_fail(AMT_ERR_PRECONDITION, "empty memory extents");
+    int ndev = 0;
+    AMT_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return amt_fail(AMT_ERR_NO_DEVICE, "no HIP device visible");
+    amt_domain *d = new (std::nothrow) amt_domain;
+    if (!d) return amt_fail(AMT_ERR_ALLOC, "host allocation failed");
+    d->dtype_bytes = dtype_bytes;
+    d->periodic_x = periodic_x; d->specified = specified; d->nested = nested;
+    d->ids = ids; d->ide = ide; d->jds = jds; d->jde = jde; d->kde = kde;
+    d->ims = ims; d->ime = ime; d->jms = jms; d->jme = jme; d->kms = kms; d->kme = kme;
+    d->its = its; d->ite = ite; d->jts = jts; d->jte = jte; d->kts = kts; d->kte = kte;
+    hipError_t e = hipGetDevice(&d->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&d->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&d->ev1);
+    for (int f = 0; f < AMT_F_COUNT && e == hipSuccess; ++f)
+        e = hipMalloc(&d->field[f], d->count(f) * (size_t)dtype_bytes);
+    if (e != hipSuccess) {
+        amt_domain_destroy(d);
+        return amt_fail(e == hipErrorOutOfMemory ? AMT_ERR_ALLOC : AMT_ERR_HIP,
+                        "amt_domain_create: %s", hipGetErrorString(e));
+    }
+    *out = d;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_set_scalars(amt_domain *d, double rdx, double rdy, double dts, double epssm)
+{
+    if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    d->rdx = rdx; d->rdy = rdy; d->dts = dts; d->epssm = epssm;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_set_variant(amt_domain *d, int variant)
+{
+    if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    if (variant < AMT_VARIANT_AUTO || variant > AMT_VARIANT_MARCH)
+        return amt_fail(AMT_ERR_INVALID_ARG, "unknown variant %d", variant);
+    d->variant = variant;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_upload(amt_domain *d, int field, const void *host)
+{
+    if (!d || !host || field < 0 || field >= AMT_F_COUNT) return amt_fail(AMT_ERR_INVALID_ARG, "bad upload argument");
+    DeviceScope scope(d->device);
+    AMT_HIP(hipMemcpyAsync(d->field[field], host, d->count(field) * d->dtype_bytes, hipMemcpyHostToDevice, d->stream));
+    AMT_HIP(hipStreamSynchronize(d->stream));
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_download(amt_domain *d, int field, void *host)
+{
+    if (!d || !host || field < 0 || field >= AMT_F_COUNT) return amt_fail(AMT_ERR_INVALID_ARG, "bad download argument");
+    DeviceScope scope(d->device);
+    AMT_HIP(hipMemcpyAsync(host, d->field[field], d->count(field) * d->dtype_bytes, hipMemcpyDeviceToHost, d->stream));
+    AMT_HIP(hipStreamSynchronize(d->stream));
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,
+                                         long gi0, long gk0, long gj0,
+                                         long gidim, long gkdim, long gjdim)
+{
+    if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    DeviceScope scope(d->device);
+    const long idim = d->ime - d->ims + 1, kdim = d->kme - d->kms + 1, jdim = d->jme - d->jms + 1;
+    for (int f = 0; f < AMT_F_COUNT; ++f) {
+        int rc = amt_synth_fill_device(d->stream, f, d->dtype_bytes, d->field[f], seed,
+                                       idim, kdim, jdim, gi0, gk0, gj0, gidim, gkdim, gjdim);
+        if (rc) return rc;
+    }
+    return AMT_OK;
+}
+
+
+template <typename T>
+static int amt_domain_step_t(amt_domain *d, int n_sweeps)
+{
+    AmtArgs<T> a;
+    amt_domain_args<T>(d, a);
+    for (int s = 0; s < n_sweeps; ++s) {
+        int rc = amt_device_call<T>(d->stream, d->variant, a);
+        if (rc) return rc;
+    }
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_step(amt_domain *d, int n_sweeps)
+{
+    if (!d || n_sweeps < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad step argument");
+    DeviceScope scope(d->device);
+    return d->dtype_bytes == 8 ? amt_domain_step_t<double>(d, n_sweeps) : amt_domain_step_t<float>(d, n_sweeps);
+}
+
+extern "C" int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_total)
+{
+    if (!d || n_sweeps < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad step argument");
+    DeviceScope scope(d->device);
+    AMT_HIP(hipEventRecord(d->ev0, d->stream));
+    int rc = amt_domain_step(d, n_sweeps);
+    if (rc) return rc;
+    AMT_HIP(hipEventRecord(d->ev1, d->stream));
+    AMT_HIP(hipEventSynchronize(d->ev1));
+    float ms = 0.f;
+    AMT_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+    if (ms_total) *ms_total = ms;
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_sync(amt_domain *d)
+{
+    if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    DeviceScope scope(d->device);
+    AMT_HIP(hipStreamSynchronize(d->stream));
+    return AMT_OK;
+}
+
+extern "C" void *amt_domain_field_ptr(amt_domain *d, int field)
+{
+    if (!d || field < 0 || field >= AMT_F_COUNT) return nullptr;
+    return d->field[field];
+}
+
+extern "C" void *amt_domain_stream(amt_domain *d) { return d ? (void *)d->stream : nullptr; }
+

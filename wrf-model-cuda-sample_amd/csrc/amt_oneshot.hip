@@ -1,0 +1,473 @@
+// amt_oneshot.hip -- the one-shot host drop-in amt_advance_mu_t_f32/_f64: host arrays in, host
+// arrays out (the job of the reference's CUDA wrapper, advance_mu_t_no_async.cu:178-423: alloc,
+// H2D, launch, D2H, free), streamed.
+#include "amt_internal.h"
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+namespace {
+int amt_env_flag(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+// What a one-shot call needs on the device besides the data: three streams, six events and a
+// buffer arena.  Creating and destroying them costs ~10 ms per call -- more than the whole call
+// at WRF patch sizes -- so each host thread keeps its own set between calls (per thread: WRF
+// calls advance_mu_t from OpenMP tile threads).  amt_host_release() frees the calling thread's.
+struct HostWorkspace {
+    int device = -1;
+    hipStream_t up = nullptr, comp = nullptr, down = nullptr;
+    hipEvent_t uploaded[2] = {}, computed[2] = {}, drained[2] = {};
+    char *arena = nullptr;
+    size_t arena_size = 0, used = 0;
+    char *stage = nullptr;                                   // page-locked host staging (packed calls)
+    size_t stage_size = 0;
+    static constexpr size_t keep_limit = (size_t)1 << 30;   // larger arenas are not kept between calls
+
+    void release()
+    {
+        if (device < 0) return;
+        int prev = -1;
+        const bool sw = hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
+        for (hipStream_t st : {up, comp, down})
+            if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        for (int s = 0; s < 2; ++s)
+            for (hipEvent_t e : {uploaded[s], computed[s], drained[s]})
+                if (e) (void)hipEventDestroy(e);
+        if (arena) (void)hipFree(arena);
+        if (stage) (void)hipHostFree(stage);
+        if (sw) (void)hipSetDevice(prev);
+        *this = HostWorkspace();
+    }
+    // A worker thread's workspace is freed when the thread ends.  The main thread's destructor
+    // runs at process exit only, possibly from a signal path with a HIP call on the stack: leave
+    // that one to the operating system.
+    ~HostWorkspace()
+    {
+        if ((long)syscall(SYS_gettid) != (long)getpid()) release();
+    }
+
+    hipError_t prepare(int dev, size_t bytes)
+    {
+        if (device != dev) {
+            release();
+            device = dev;
+            hipError_t e = hipSuccess;
+            for (hipStream_t *st : {&up, &comp, &down})
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+            for (int s = 0; s < 2; ++s)
+                for (hipEvent_t *ev : {&uploaded[s], &computed[s], &drained[s]})
+                    if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+            if (e != hipSuccess) { release(); return e; }
+        }
+        if (bytes > arena_size) {
+            if (arena) (void)hipFree(arena);
+            arena = nullptr;
+            arena_size = 0;
+            hipError_t e = hipMalloc((void **)&arena, bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); arena = nullptr; return e; }
+            arena_size = bytes;
+        }
+        used = 0;
+        return hipSuccess;
+    }
+    void *take(size_t bytes)
+    {
+        const size_t off = (used + 255) & ~(size_t)255;
+        used = off + bytes;
+        return arena + off;
+    }
+    hipError_t stage_reserve(size_t bytes)
+    {
+        if (bytes <= stage_size) return hipSuccess;
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr;
+        stage_size = 0;
+        hipError_t e = hipHostMalloc((void **)&stage, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); stage = nullptr; return e; }
+        stage_size = bytes;
+        return hipSuccess;
+    }
+    // end of a call: nothing may still be in flight towards the caller's arrays
+    void finish()
+    {
+        for (hipStream_t st : {up, comp, down})
+            if (st) (void)hipStreamSynchronize(st);
+        if (arena_size > keep_limit) {
+            (void)hipFree(arena);
+            arena = nullptr;
+            arena_size = 0;
+        }
+    }
+};
+thread_local HostWorkspace tl_workspace;
+struct WorkspaceScope {
+    HostWorkspace &ws;
+    ~WorkspaceScope() { ws.finish(); }
+};
+}  // namespace
+
+extern "C" int amt_host_release(void)
+{
+    tl_workspace.release();
+    return AMT_OK;
+}
+
+// One-shot call = upload, kernel, download.  Three regimes, chosen per call:
+//  * streamed (3-D arrays page-locked by the caller -- amt_host_pin / hipHostRegister /
+//    hipHostMalloc, once, like the reference driver's cudaHostAlloc, advance_mu_t_driver.cu:
+//    97-167): the window's j rows are cut into chunks; chunk c runs
+//      H2D (its rows + one halo row each side of the five arrays the stencil reads across rows)
+//      -> kernel -> D2H (the window's cells of ww, t, t_ave)
+//    through device buffer set c % 2, the three stages on an upload, a compute and a download
+//    stream chained by events, so that both directions of the host link stay busy;
+//  * streamed with a download thread (3-D arrays pageable, more than one chunk): a copy from or
+//    to pageable memory blocks its host thread, so the downloads are issued by a second thread
+//    (two threads drive both directions of the link at full rate, one cannot; pinning inside
+//    the call costs more than it saves: 61 vs 41 ms at 512x60x512 fp64);
+//  * packed (pageable and small -- WRF patch sizes): every blocking copy costs ~0.2 ms, 29 of
+//    them more than everything else, so the arrays are gathered into a page-locked staging
+//    buffer that mirrors the device arena and cross the link in one copy each way.
+// The 2-D and 1-D arrays (1/NK of the data) go up once before the first chunk and come down once
+// after the last, packed when they are pageable.  Chunks are legal because a row's outputs depend
+// on other rows' INPUTS only.  The reference does one synchronous piece per call and allocates
+// and frees everything around it (advance_mu_t_no_async.cu:178-306,366-423).
+static bool amt_is_pinned(const void *ptr)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+extern "C" int amt_host_pin(void *ptr, size_t bytes)
+{
+    if (!ptr) return amt_fail(AMT_ERR_INVALID_ARG, "null pointer");
+    AMT_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return AMT_OK;
+}
+
+extern "C" int amt_host_unpin(void *ptr)
+{
+    if (!ptr) return amt_fail(AMT_ERR_INVALID_ARG, "null pointer");
+    AMT_HIP(hipHostUnregister(ptr));
+    return AMT_OK;
+}
+
+template <typename T>
+static int amt_host_call(const AmtArgs<T> &h)
+{
+    AmtParams<T> p;
+    AmtWindow w;
+    bool empty = false;
+    int rc = amt_build_params(h, p, w, &empty);
+    if (rc != AMT_OK || empty) return rc;
+    int ndev = 0;
+    AMT_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return amt_fail(AMT_ERR_NO_DEVICE, "no HIP device visible");
+    int device = 0;
+    AMT_HIP(hipGetDevice(&device));
+
+    const long idim = p.idim, kdim = p.kdim;
+    const size_t r3 = (size_t)idim * kdim, r2 = (size_t)idim, n1 = (size_t)kdim;   // elements per j row
+    const int nj = w.j_end - w.j_start + 1;
+    const size_t ni = (size_t)(p.i1 - p.i0 + 1);
+
+    // `out`: assigned by the routine; `in`: read by it (t_ave :210 and muave, muts, mudf :152-156
+    // are assigned before any use; of ww only level 1 is read, :161)
+    struct Item { const T *host; int rank; bool halo; bool out; bool in; };
+    enum { F_WW = 0 };
+    const Item items[26] = {
+        {h.ww, 3, false, true, true}, {h.ww_1, 3, false, false, true}, {h.u, 3, false, false, true},
+        {h.u_1, 3, false, false, true}, {h.v, 3, true, false, true}, {h.v_1, 3, true, false, true},
+        {h.mu, 2, false, true, true}, {h.mut, 2, false, false, true}, {h.muave, 2, false, true, false},
+        {h.muts, 2, false, true, false}, {h.muu, 2, false, false, true}, {h.muv, 2, true, false, true},
+        {h.mudf, 2, false, true, false}, {h.t, 3, false, true, true}, {h.t_1, 3, true, false, true},
+        {h.t_ave, 3, false, true, false}, {h.ft, 3, false, false, true}, {h.mu_tend, 2, false, false, true},
+        {h.dnw, 1, false, false, true}, {h.fnm, 1, false, false, true}, {h.fnp, 1, false, false, true},
+        {h.rdnw, 1, false, false, true}, {h.msfuy, 2, false, false, true}, {h.msfvx_inv, 2, true, false, true},
+        {h.msftx, 2, false, false, true}, {h.msfty, 2, false, false, true},
+    };
+    bool pinned = true, pinned_small = true;                  // the 3-D arrays / the 2-D and 1-D ones
+    for (const Item &it : items) (it.rank == 3 ? pinned : pinned_small) &= amt_is_pinned(it.host);
+
+    // chunking: ~320 MB of 3-D input per chunk (measured best at 1024x60x1024 fp64)
+    const char *env_rows = getenv("AMT_STREAM_ROWS");         // test/tuning knob: rows per chunk
+    const bool may_thread = !pinned && amt_env_flag("AMT_STREAM_THREAD", 1);
+    long rows = env_rows ? atol(env_rows) : (pinned || may_thread) ? (long)((320u << 20) / (r3 * sizeof(T) * 10) + 1) : (long)nj;
+    if (rows < 1) rows = 1;
+    if (rows > nj) rows = nj;
+    const int nchunk = (int)((nj + rows - 1) / rows);
+    const int nset = nchunk > 1 ? 2 : 1;
+    const size_t crow = (size_t)rows + 2;                     // device rows per 3-D buffer set
+    const size_t wrow = (size_t)nj + 2;                       // device rows of a 2-D array: the window's +-1
+    const bool threaded = may_thread && nchunk > 1;
+
+    // packing (see above): the small arrays when they are pageable, the 3-D ones too when they
+    // are pageable, one chunk and small
+    const size_t small_bytes = 12 * (r2 * wrow * sizeof(T) + 256) + 4 * (n1 * sizeof(T) + 256);
+    const size_t big_bytes = (size_t)nset * 10 * (r3 * crow * sizeof(T) + 256);
+    const bool allow_pack = amt_env_flag("AMT_STREAM_PACK", 1) != 0;
+    const bool pack_small = allow_pack && !pinned_small && small_bytes <= ((size_t)32 << 20);
+    const bool pack_big = pack_small && !pinned && nchunk == 1 && big_bytes <= ((size_t)64 << 20);
+
+    const bool trace = getenv("AMT_STREAM_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+
+    // arena layout: [3-D inputs][3-D outputs][small outputs][small inputs] -- what comes down is
+    // one contiguous range, and so is everything a packed call sends up
+    HostWorkspace &ws = tl_workspace;
+    {
+        const hipError_t e = ws.prepare(device, big_bytes + small_bytes);
+        if (e == hipErrorOutOfMemory) return amt_fail(AMT_ERR_ALLOC, "hipMalloc of %zu bytes failed", big_bytes + small_bytes);
+        AMT_HIP(e);
+    }
+    WorkspaceScope scope{ws};                                 // drains the three streams on every way out
+    T *dev[2][26];
+    size_t out3_begin = 0, small_begin = 0, small_out_end = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        if (pass == 1) out3_begin = (ws.used + 255) & ~(size_t)255;
+        if (pass == 2) small_begin = (ws.used + 255) & ~(size_t)255;
+        if (pass == 3) small_out_end = (ws.used + 255) & ~(size_t)255;
+        for (int f = 0; f < 26; ++f) {
+            const Item &it = items[f];
+            const bool big = it.rank == 3;
+            if (big != (pass < 2) || it.out != (pass == 1 || pass == 2)) continue;
+            if (big) {
+                for (int s = 0; s < nset; ++s) dev[s][f] = static_cast<T *>(ws.take(r3 * crow * sizeof(T)));
+                if (nset == 1) dev[1][f] = dev[0][f];
+            } else {
+                dev[0][f] = dev[1][f] = static_cast<T *>(ws.take((it.rank == 2 ? r2 * wrow : n1) * sizeof(T)));
+            }
+        }
+    }
+    const size_t arena_end = ws.used;
+    // staging buffer: mirrors the arena from stage_base on
+    const size_t stage_base = pack_big ? 0 : small_begin;
+    char *stage = nullptr;
+    if (pack_small) {
+        const hipError_t e = ws.stage_reserve(arena_end - stage_base);
+        if (e == hipErrorOutOfMemory) return amt_fail(AMT_ERR_ALLOC, "hipHostMalloc of %zu bytes failed", arena_end - stage_base);
+        AMT_HIP(e);
+        stage = ws.stage;
+    }
+    auto staged = [&](const T *devptr) -> T * {               // the staging twin of a device address
+        return reinterpret_cast<T *>(stage + ((reinterpret_cast<const char *>(devptr) - ws.arena) - stage_base));
+    };
+    const double t_alloc = now();
+    const hipStream_t up = ws.up, comp = ws.comp, down = ws.down;
+
+    // ---- the 1-D and 2-D arrays, once -----------------------------------------------------------
+    for (int f = 0; f < 26; ++f) {
+        const Item &it = items[f];
+        if (it.rank == 3 || !it.in) continue;                 // muave, muts, mudf: outputs only
+        const size_t n = it.rank == 1 ? n1 : r2 * wrow;
+        const T *src = it.rank == 1 ? it.host : it.host + (size_t)(w.j_start - 1 - h.jms) * r2;
+        if (pack_small) memcpy(staged(dev[0][f]), src, n * sizeof(T));
+        else AMT_HIP(hipMemcpyAsync(dev[0][f], src, n * sizeof(T), hipMemcpyHostToDevice, up));
+    }
+    if (!pack_small)                                          // whole-row downloads: keep the other cells' bits
+        for (int f = 0; f < 26; ++f) {
+            const Item &it = items[f];
+            if (it.rank != 2 || it.in) continue;
+            AMT_HIP(hipMemcpyAsync(dev[0][f], it.host + (size_t)(w.j_start - 1 - h.jms) * r2, r2 * wrow * sizeof(T),
+                                   hipMemcpyHostToDevice, up));
+        }
+    if (pack_small && !pack_big)
+        AMT_HIP(hipMemcpyAsync(ws.arena + small_begin, stage, arena_end - small_begin, hipMemcpyHostToDevice, up));
+
+    // chunk c: rows c0..c1 of the window
+    auto chunk_rows = [&](int c, int &c0, int &c1) {
+        c0 = w.j_start + (int)(c * rows);
+        c1 = (c0 + rows - 1 < w.j_end) ? (int)(c0 + rows - 1) : w.j_end;
+    };
+    // chunk c's window cells of ww, t, t_ave: nothing else of the host arrays is touched
+    auto download = [&](int c) -> hipError_t {
+        const int s = c % nset;
+        int c0, c1;
+        chunk_rows(c, c0, c1);
+        hipError_t e = hipStreamWaitEvent(down, ws.computed[s], 0);
+        for (int f = 0; f < 26 && p.nk > 0 && e == hipSuccess; ++f) {
+            const Item &it = items[f];
+            if (!it.out || it.rank != 3) continue;
+            hipMemcpy3DParms cp;
+            memset(&cp, 0, sizeof cp);
+            cp.srcPtr = make_hipPitchedPtr(dev[s][f], (size_t)idim * sizeof(T), (size_t)idim, (size_t)kdim);
+            cp.dstPtr = make_hipPitchedPtr(const_cast<T *>(it.host), (size_t)idim * sizeof(T), (size_t)idim, (size_t)kdim);
+            cp.srcPos = make_hipPos((size_t)p.i0 * sizeof(T), (size_t)p.k1, 1);
+            cp.dstPos = make_hipPos((size_t)p.i0 * sizeof(T), (size_t)p.k1, (size_t)(c0 - h.jms));
+            cp.extent = make_hipExtent(ni * sizeof(T), (size_t)p.nk, (size_t)(c1 - c0 + 1));
+            cp.kind = hipMemcpyDeviceToHost;
+            e = hipMemcpy3DAsync(&cp, down);
+        }
+        return e != hipSuccess ? e : hipEventRecord(ws.drained[s], down);
+    };
+
+    // download thread: takes chunks in order as the main thread reports them launched, reports
+    // them drained so that their buffer set can be reused
+    struct Downloader {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        int launched = 0, drained = 0;
+        bool stop = false;
+        hipError_t err = hipSuccess;
+        ~Downloader()
+        {
+            { std::lock_guard<std::mutex> lk(m); stop = true; }
+            cv.notify_all();
+            if (th.joinable()) th.join();
+        }
+    } dl;
+    if (threaded) {
+        dl.th = std::thread([&, device] {
+            hipError_t e = hipSetDevice(device);
+            for (int c = 0; c < nchunk; ++c) {
+                {
+                    std::unique_lock<std::mutex> lk(dl.m);
+                    dl.cv.wait(lk, [&] { return dl.stop || dl.launched > c; });
+                    if (dl.launched <= c) return;
+                }
+                if (e == hipSuccess) e = download(c);
+                if (e == hipSuccess) e = hipStreamSynchronize(down);
+                {
+                    std::lock_guard<std::mutex> lk(dl.m);
+                    if (e != hipSuccess) dl.err = e;
+                    dl.drained = c + 1;
+                }
+                dl.cv.notify_all();
+            }
+        });
+    }
+
+    // ---- the chunks -----------------------------------------------------------------------------
+    for (int c = 0; c < nchunk; ++c) {
+        const int s = c % nset;
+        int c0, c1;
+        chunk_rows(c, c0, c1);
+        const int ja = c0 - 1;                                // device row 0 <-> Fortran row ja
+        if (c >= nset) {                                      // set s is free again
+            if (threaded) {
+                std::unique_lock<std::mutex> lk(dl.m);
+                dl.cv.wait(lk, [&] { return dl.drained > c - nset; });
+                if (dl.err != hipSuccess) break;
+            } else {
+                AMT_HIP(hipStreamWaitEvent(up, ws.drained[s], 0));
+            }
+        }
+        for (int f = 0; f < 26; ++f) {
+            const Item &it = items[f];
+            if (it.rank != 3 || !it.in) continue;
+            if (f == F_WW) {                                  // level 1 only
+                const T *src = it.host + (size_t)(c0 - h.jms) * r3 + (size_t)p.k1 * idim;
+                T *dst = dev[s][f] + r3 + (size_t)p.k1 * idim;
+                if (pack_big)
+                    for (int j = c0; j <= c1; ++j)
+                        memcpy(staged(dst) + (size_t)(j - c0) * r3, src + (size_t)(j - c0) * r3, (size_t)idim * sizeof(T));
+                else
+                    AMT_HIP(hipMemcpy2DAsync(dst, r3 * sizeof(T), src, r3 * sizeof(T), (size_t)idim * sizeof(T),
+                                             (size_t)(c1 - c0 + 1), hipMemcpyHostToDevice, up));
+                continue;
+            }
+            const int lo = it.halo ? c0 - 1 : c0, hi = it.halo ? c1 + 1 : c1;
+            const size_t n = (size_t)(hi - lo + 1) * r3 * sizeof(T);
+            if (pack_big) memcpy(staged(dev[s][f]) + (size_t)(lo - ja) * r3, it.host + (size_t)(lo - h.jms) * r3, n);
+            else AMT_HIP(hipMemcpyAsync(dev[s][f] + (size_t)(lo - ja) * r3, it.host + (size_t)(lo - h.jms) * r3, n,
+                                        hipMemcpyHostToDevice, up));
+        }
+        if (pack_big)                                         // one chunk: everything, small arrays included
+            AMT_HIP(hipMemcpyAsync(ws.arena, stage, arena_end, hipMemcpyHostToDevice, up));
+        AMT_HIP(hipEventRecord(ws.uploaded[s], up));
+        AmtArgs<T> d = h;
+        T *q[26];
+        for (int f = 0; f < 26; ++f)                          // every array as if it began at row ja
+            q[f] = items[f].rank == 2 ? dev[0][f] + (size_t)(ja - (w.j_start - 1)) * r2 : dev[s][f];
+        d.ww = q[0]; d.ww_1 = q[1]; d.u = q[2]; d.u_1 = q[3]; d.v = q[4]; d.v_1 = q[5]; d.mu = q[6];
+        d.mut = q[7]; d.muave = q[8]; d.muts = q[9]; d.muu = q[10]; d.muv = q[11]; d.mudf = q[12];
+        d.t = q[13]; d.t_1 = q[14]; d.t_ave = q[15]; d.ft = q[16]; d.mu_tend = q[17];
+        d.dnw = q[18]; d.fnm = q[19]; d.fnp = q[20]; d.rdnw = q[21]; d.msfuy = q[22];
+        d.msfvx_inv = q[23]; d.msftx = q[24]; d.msfty = q[25];
+        d.jms = ja; d.jme = c1 + 1; d.jts = c0; d.jte = c1;  // a tile of the same domain (global jds, jde)
+        AMT_HIP(hipStreamWaitEvent(comp, ws.uploaded[s], 0));
+        rc = amt_device_call<T>(comp, AMT_VARIANT_AUTO, d);
+        if (rc != AMT_OK) break;
+        AMT_HIP(hipEventRecord(ws.computed[s], comp));
+        if (threaded) {
+            { std::lock_guard<std::mutex> lk(dl.m); dl.launched = c + 1; }
+            dl.cv.notify_all();
+        } else if (!pack_big) {
+            AMT_HIP(download(c));
+        }
+    }
+    if (threaded) {                                           // all launched chunks drain, then the thread ends
+        { std::lock_guard<std::mutex> lk(dl.m); dl.stop = true; }
+        dl.cv.notify_all();
+        dl.th.join();
+        if (dl.err != hipSuccess && rc == AMT_OK)
+            rc = amt_fail(AMT_ERR_HIP, "download of a chunk failed: %s", hipGetErrorString(dl.err));
+    }
+
+    // ---- the outputs that come down once, after the last kernel -----------------------------------
+    if (rc == AMT_OK) {
+        AMT_HIP(hipStreamWaitEvent(down, ws.computed[(nchunk - 1) % nset], 0));
+        if (pack_small) {
+            const size_t from = pack_big ? out3_begin : small_begin;
+            AMT_HIP(hipMemcpyAsync(stage + (from - stage_base), ws.arena + from, small_out_end - from,
+                                   hipMemcpyDeviceToHost, down));
+            AMT_HIP(hipStreamSynchronize(down));
+            for (int f = 0; f < 26; ++f) {                    // scatter: the window's cells only
+                const Item &it = items[f];
+                if (!it.out) continue;
+                if (it.rank == 2) {
+                    for (int j = w.j_start; j <= w.j_end; ++j)
+                        memcpy(const_cast<T *>(it.host) + (size_t)(j - h.jms) * r2 + p.i0,
+                               staged(dev[0][f]) + (size_t)(j - w.j_start + 1) * r2 + p.i0, ni * sizeof(T));
+                } else if (pack_big) {
+                    for (int j = w.j_start; j <= w.j_end; ++j)
+                        for (int k = 0; k < p.nk; ++k) {
+                            const size_t e = (size_t)(p.k1 + k) * idim + p.i0;
+                            memcpy(const_cast<T *>(it.host) + (size_t)(j - h.jms) * r3 + e,
+                                   staged(dev[0][f]) + (size_t)(j - w.j_start + 1) * r3 + e, ni * sizeof(T));
+                        }
+                }
+            }
+        } else {
+            for (int f = 0; f < 26; ++f) {
+                const Item &it = items[f];
+                if (!it.out || it.rank != 2) continue;
+                AMT_HIP(hipMemcpyAsync(const_cast<T *>(it.host) + (size_t)(w.j_start - h.jms) * r2, dev[0][f] + r2,
+                                       (size_t)nj * r2 * sizeof(T), hipMemcpyDeviceToHost, down));
+            }
+        }
+    }
+    const double t_enq = now();
+    for (hipStream_t st : {up, comp, down}) {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess && rc == AMT_OK)
+            rc = amt_fail(AMT_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    }
+    if (trace)
+        fprintf(stderr, "amt one-shot: %d chunk(s) of %ld rows, 3-D %s%s, small arrays %s; alloc %.2f ms, enqueue %.2f ms, drain %.2f ms\n",
+                nchunk, rows, pinned ? "pinned" : pack_big ? "packed" : "pageable", threaded ? " + download thread" : "",
+                pinned_small ? "pinned" : pack_small ? "packed" : "pageable", t_alloc - t_begin, t_enq - t_alloc, now() - t_enq);
+    return rc;
+}
+
+extern "C" int amt_advance_mu_t_f32(AMT_SIG(float))
+{
+    AMT_PACK_ARGS(float)
+    return amt_host_call<float>(a);
+}
+extern "C" int amt_advance_mu_t_f64(AMT_SIG(double))
+{
+    AMT_PACK_ARGS(double)
+    return amt_host_call<double>(a);
+}

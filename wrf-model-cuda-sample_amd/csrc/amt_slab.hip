@@ -1,0 +1,326 @@
+// amt_slab.hip -- j-slab stepping with RCCL halos, amt_slab_* (include/amt_advance_mu_t.h section 5).
+#include "amt_internal.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <chrono>
+#include <mutex>
+#include <thread>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+// ---------------------------------------------------------------------------
+// the native twin of patch.SlabStepper, for C / Fortran
+//     hosts that run one process per GPU (the reference splits j over its
+//     GPUs inside one process with host-sourced halos, advance_mu_t_no_async.cu:108-162).
+//     RCCL is opened with dlopen on first use: the library has no link-time dependency on it
+//     and single-GPU users never load it.
+// ---------------------------------------------------------------------------
+namespace {
+struct AmtRccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+AmtRccl g_rccl;
+std::mutex g_rccl_mutex;
+
+int amt_rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mutex);
+    if (g_rccl.lib) return AMT_OK;
+    const char *names[] = {getenv("AMT_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names)
+        if (n && *n && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!lib) return amt_fail(AMT_ERR_COMM, "cannot open librccl: %s", dlerror());
+    AmtRccl r;
+    r.lib = lib;
+    bool ok = true;
+    auto sym = [&](const char *name) { void *p = dlsym(lib, name); ok = ok && p; return p; };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(lib); return amt_fail(AMT_ERR_COMM, "librccl lacks a send/recv entry point"); }
+    g_rccl = r;
+    return AMT_OK;
+}
+}  // namespace
+
+#define AMT_NCCL(call)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return amt_fail(AMT_ERR_COMM, "%s failed: %s (%s:%d)", #call,                       \
+                            g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", __FILE__, __LINE__); \
+    } while (0)
+
+static_assert(AMT_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "amt_comm_unique_id hands out an ncclUniqueId");
+
+extern "C" int amt_set_device(int device)
+{
+    AMT_HIP(hipSetDevice(device));
+    return AMT_OK;
+}
+
+extern "C" int amt_comm_unique_id(void *id_out)
+{
+    if (!id_out) return amt_fail(AMT_ERR_INVALID_ARG, "null id buffer");
+    int rc = amt_rccl_load();
+    if (rc) return rc;
+    ncclUniqueId id;
+    AMT_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return AMT_OK;
+}
+
+// Rendezvous for hosts without MPI: rank 0 creates the id and publishes it as `path` (written
+// under a temporary name, then renamed), the other ranks wait for the file.  A file left by an
+// earlier launch must not be taken for this one's: rank 0 removes it first, and the others ignore
+// files last written more than a minute before they started waiting (use a fresh path per launch,
+// e.g. derived from the launcher's port, when relaunching faster than that).
+extern "C" int amt_comm_rendezvous_file(const char *path, int rank, double timeout_s, void *id_out)
+{
+    if (!path || !*path || !id_out || rank < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad rendezvous argument");
+    if (rank == 0) {
+        (void)unlink(path);
+        int rc = amt_comm_unique_id(id_out);
+        if (rc) return rc;
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) return amt_fail(AMT_ERR_COMM, "cannot write %s", tmp.c_str());
+        const size_t n = fwrite(id_out, 1, AMT_UNIQUE_ID_BYTES, f);
+        fclose(f);
+        if (n != AMT_UNIQUE_ID_BYTES || rename(tmp.c_str(), path) != 0)
+            return amt_fail(AMT_ERR_COMM, "cannot publish %s", path);
+        return AMT_OK;
+    }
+    const time_t entered = time(nullptr);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        struct stat st;
+        if (stat(path, &st) == 0 && st.st_mtime >= entered - 60) {
+            if (FILE *f = fopen(path, "rb")) {
+                const size_t n = fread(id_out, 1, AMT_UNIQUE_ID_BYTES, f);
+                fclose(f);
+                if (n == AMT_UNIQUE_ID_BYTES) return AMT_OK;
+            }
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+            return amt_fail(AMT_ERR_COMM, "no rendezvous file %s after %.0f s", path, timeout_s);
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+}
+
+struct amt_slab {
+    amt_domain *dom = nullptr;
+    int rank = 0, world = 1;
+    int below = -1, above = -1;          // neighbour ranks, -1 = none
+    bool overlap = true;
+    ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t inputs_final = nullptr, edges_done = nullptr, t0 = nullptr, t1 = nullptr;
+};
+
+extern "C" int amt_slab_destroy(amt_slab *s)
+{
+    if (!s) return AMT_OK;
+    DeviceScope scope(s->dom ? s->dom->device : 0);
+    if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
+    if (s->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->comm);
+    for (hipEvent_t e : {s->inputs_final, s->edges_done, s->t0, s->t1})
+        if (e) (void)hipEventDestroy(e);
+    if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
+    delete s;
+    return AMT_OK;
+}
+
+extern "C" int amt_slab_create(amt_slab **out, amt_domain *dom, int rank, int world, const void *unique_id, int flags)
+{
+    if (!out) return amt_fail(AMT_ERR_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    if (!dom || world < 1 || rank < 0 || rank >= world) return amt_fail(AMT_ERR_INVALID_ARG, "bad slab argument");
+    const bool loopback = (flags & AMT_SLAB_LOOPBACK) != 0;
+    if (loopback && world != 1) return amt_fail(AMT_ERR_INVALID_ARG, "AMT_SLAB_LOOPBACK is a one-rank test mode");
+    const bool comm_needed = world > 1 || loopback;
+    if (comm_needed && !unique_id) return amt_fail(AMT_ERR_INVALID_ARG, "a communicator needs the unique id");
+    if (comm_needed && (dom->jts - 1 < dom->jms || dom->jte + 1 > dom->jme))
+        return amt_fail(AMT_ERR_PRECONDITION, "a slab holds one halo row below jts and above jte");
+    amt_slab *s = new (std::nothrow) amt_slab;
+    if (!s) return amt_fail(AMT_ERR_ALLOC, "host allocation failed");
+    s->dom = dom; s->rank = rank; s->world = world;
+    s->overlap = !(flags & AMT_SLAB_NO_OVERLAP);
+    s->below = loopback ? rank : rank > 0 ? rank - 1 : -1;
+    s->above = loopback ? rank : rank < world - 1 ? rank + 1 : -1;
+    DeviceScope scope(dom->device);
+    hipError_t e = hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking);
+    for (hipEvent_t *ev : {&s->inputs_final, &s->edges_done})
+        if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    for (hipEvent_t *ev : {&s->t0, &s->t1})
+        if (e == hipSuccess) e = hipEventCreate(ev);
+    if (e != hipSuccess) {
+        amt_slab_destroy(s);
+        return amt_fail(AMT_ERR_HIP, "amt_slab_create: %s", hipGetErrorString(e));
+    }
+    if (comm_needed) {
+        int rc = amt_rccl_load();
+        if (rc) { amt_slab_destroy(s); return rc; }
+        ncclUniqueId id;
+        memcpy(&id, unique_id, sizeof id);
+        ncclResult_t r = g_rccl.CommInitRank(&s->comm, world, id, rank);
+        if (r != ncclSuccess) {
+            s->comm = nullptr;
+            amt_slab_destroy(s);
+            return amt_fail(AMT_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+        }
+    }
+    *out = s;
+    return AMT_OK;
+}
+
+namespace {
+// rows that cross a slab boundary: row jte+1 of these comes from the rank above (its row jts) ...
+const int kHaloFromAbove[] = {AMT_F_V, AMT_F_V_1, AMT_F_T_1, AMT_F_MUV, AMT_F_MSFVX_INV};   // :143-144, :241
+// ... and row jts-1 of t_1 from the rank below (its row jte), :242
+const int kHaloFromBelow[] = {AMT_F_T_1};
+
+int amt_slab_enqueue_exchange(amt_slab *s, hipStream_t stream)
+{
+    if (s->below < 0 && s->above < 0) return AMT_OK;
+    amt_domain *d = s->dom;
+    const size_t idim = d->ime - d->ims + 1, kdim = d->kme - d->kms + 1;
+    const ncclDataType_t dt = d->dtype_bytes == 8 ? ncclDouble : ncclFloat;
+    auto row = [&](int f, int j, size_t &count) -> void * {
+        count = amt_field_rank(f) == 3 ? idim * kdim : idim;
+        return static_cast<char *>(d->field[f]) + (size_t)(j - d->jms) * count * d->dtype_bytes;
+    };
+    size_t n = 0;
+    // per pair of ranks the order of sends matches the order of receives on the other side
+    AMT_NCCL(g_rccl.GroupStart());
+    if (s->below >= 0)
+        for (int f : kHaloFromAbove) { void *q = row(f, d->jts, n); AMT_NCCL(g_rccl.Send(q, n, dt, s->below, s->comm, stream)); }
+    if (s->above >= 0)
+        for (int f : kHaloFromBelow) { void *q = row(f, d->jte, n); AMT_NCCL(g_rccl.Send(q, n, dt, s->above, s->comm, stream)); }
+    if (s->above >= 0)
+        for (int f : kHaloFromAbove) { void *q = row(f, d->jte + 1, n); AMT_NCCL(g_rccl.Recv(q, n, dt, s->above, s->comm, stream)); }
+    if (s->below >= 0)
+        for (int f : kHaloFromBelow) { void *q = row(f, d->jts - 1, n); AMT_NCCL(g_rccl.Recv(q, n, dt, s->below, s->comm, stream)); }
+    AMT_NCCL(g_rccl.GroupEnd());
+    return AMT_OK;
+}
+
+template <typename T>
+int amt_slab_tile(amt_slab *s, hipStream_t stream, int jts, int jte)
+{
+    if (jte < jts) return AMT_OK;
+    AmtArgs<T> a;
+    amt_domain_args<T>(s->dom, a);
+    a.jts = jts; a.jte = jte;
+    return amt_device_call<T>(stream, s->dom->variant, a);
+}
+
+template <typename T>
+int amt_slab_step_t(amt_slab *s, int n_sweeps)
+{
+    amt_domain *d = s->dom;
+    const int jlo = d->jts, jhi = d->jte;
+    const bool lo = s->below >= 0, hi = s->above >= 0;
+    for (int sweep = 0; sweep < n_sweeps; ++sweep) {
+        int rc = AMT_OK;
+        if (!lo && !hi) {
+            rc = amt_slab_tile<T>(s, d->stream, jlo, jhi);
+            if (rc) return rc;
+            continue;
+        }
+        // rows that read a neighbour's data: jlo (slab below), jhi (slab above); the rest is interior
+        const int in_lo = jlo + (lo ? 1 : 0), in_hi = jhi - (hi ? 1 : 0);
+        hipStream_t edge_stream = s->overlap ? s->comm_stream : d->stream;
+        if (s->overlap) {
+            AMT_HIP(hipEventRecord(s->inputs_final, d->stream));          // this sub-step's inputs are final
+            AMT_HIP(hipStreamWaitEvent(s->comm_stream, s->inputs_final, 0));
+            rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi);              // interior overlaps the exchange
+            if (rc) return rc;
+        }
+        rc = amt_slab_enqueue_exchange(s, edge_stream);
+        if (rc) return rc;
+        if (!s->overlap) {
+            rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi);
+            if (rc) return rc;
+        }
+        if (lo) { rc = amt_slab_tile<T>(s, edge_stream, jlo, jlo < jhi ? jlo : jhi); if (rc) return rc; }
+        if (hi && (jhi > jlo || !lo)) { rc = amt_slab_tile<T>(s, edge_stream, jhi, jhi); if (rc) return rc; }
+        if (s->overlap) {
+            AMT_HIP(hipEventRecord(s->edges_done, s->comm_stream));
+            AMT_HIP(hipStreamWaitEvent(d->stream, s->edges_done, 0));
+        }
+    }
+    return AMT_OK;
+}
+}  // namespace
+
+extern "C" int amt_slab_exchange(amt_slab *s)
+{
+    if (!s) return amt_fail(AMT_ERR_INVALID_ARG, "null slab");
+    DeviceScope scope(s->dom->device);
+    AMT_HIP(hipEventRecord(s->inputs_final, s->dom->stream));
+    AMT_HIP(hipStreamWaitEvent(s->comm_stream, s->inputs_final, 0));
+    int rc = amt_slab_enqueue_exchange(s, s->comm_stream);
+    if (rc) return rc;
+    AMT_HIP(hipEventRecord(s->edges_done, s->comm_stream));
+    AMT_HIP(hipStreamWaitEvent(s->dom->stream, s->edges_done, 0));
+    return AMT_OK;
+}
+
+extern "C" int amt_slab_step(amt_slab *s, int n_sweeps)
+{
+    if (!s || n_sweeps < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad step argument");
+    DeviceScope scope(s->dom->device);
+    return s->dom->dtype_bytes == 8 ? amt_slab_step_t<double>(s, n_sweeps) : amt_slab_step_t<float>(s, n_sweeps);
+}
+
+extern "C" int amt_slab_step_timed(amt_slab *s, int n_sweeps, float *ms_total)
+{
+    if (!s || n_sweeps < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad step argument");
+    DeviceScope scope(s->dom->device);
+    AMT_HIP(hipEventRecord(s->t0, s->dom->stream));
+    int rc = amt_slab_step(s, n_sweeps);
+    if (rc) return rc;
+    AMT_HIP(hipEventRecord(s->t1, s->dom->stream));
+    AMT_HIP(hipEventSynchronize(s->t1));
+    float ms = 0.f;
+    AMT_HIP(hipEventElapsedTime(&ms, s->t0, s->t1));
+    if (ms_total) *ms_total = ms;
+    return AMT_OK;
+}
+
+extern "C" int amt_slab_sync(amt_slab *s)
+{
+    if (!s) return amt_fail(AMT_ERR_INVALID_ARG, "null slab");
+    DeviceScope scope(s->dom->device);
+    AMT_HIP(hipStreamSynchronize(s->comm_stream));
+    AMT_HIP(hipStreamSynchronize(s->dom->stream));
+    return AMT_OK;
+}
+
+extern "C" long amt_slab_halo_bytes(const amt_slab *s)
+{
+    if (!s) return 0;
+    const amt_domain *d = s->dom;
+    const size_t idim = d->ime - d->ims + 1, kdim = d->kme - d->kms + 1;
+    size_t per_pair = 0;
+    for (int f : kHaloFromAbove) per_pair += amt_field_rank(f) == 3 ? idim * kdim : idim;
+    for (int f : kHaloFromBelow) per_pair += amt_field_rank(f) == 3 ? idim * kdim : idim;
+    return (long)(per_pair * d->dtype_bytes * ((s->below >= 0) + (s->above >= 0)));
+}
+
