@@ -206,6 +206,24 @@ def test_fp32_run_against_fp64_oracle_at_stated_tolerance(pkg, oracle, torch_mod
         assert err <= 2e-5 * np.abs(w).max(), (n, err, np.abs(w).max())
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("nk", [1, 2, 3, 5, 6, 7, 9, 27, 35, 45, 58, 59, 61, 70])
+def test_ragged_level_counts_on_the_fast_path(pkg, oracle, torch_mod, nk, dtype):
+    """Level counts that do not fill the cell waves (nk % KPT != 0) on the aligned resident layout,
+    i.e. through the LDS-DMA flavour with virtual levels in its last wave: the top boundary
+    wdtn(kde) = 0 (:221) then falls inside a wave, and nothing beyond level nk may be stored
+    (level kte and the rows around keep their bits)."""
+    S = pkg.synth
+    b = S.domain_bounds(200, nk, 11, aligned=True)
+    host = S.make_patch(b, pkg.GridConfig(specified=True), dtype=dtype, seed=100 + nk)
+    want = host.copy()
+    oracle.advance_mu_t(*want.args())
+    dev = host.to_device("cuda:0")
+    pkg.advance_mu_t(*dev.args(), variant=pkg.VARIANT_MARCH)
+    torch_mod.cuda.synchronize()
+    assert_patch_equal(pkg, dev.to_host(), want, f"ragged nk={nk}")
+
+
 def test_empty_and_degenerate_windows(pkg, oracle, torch_mod):
     """Windows with no column (specified on a 2-cell-wide domain), one column, one row: the call
     succeeds, matches the oracle and leaves everything else untouched."""

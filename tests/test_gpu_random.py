@@ -26,9 +26,9 @@ def random_case(pkg, rng):
     kms = int(rng.choice([1, 1, 0, -2]))
     kme = kde + int(rng.integers(0, 3))
     if rng.random() < 0.4:
-        # rows a multiple of 16 bytes and a level count the LDS-DMA flavour of the march kernel takes
-        # (KPT | nk): that flavour, not the plain one, then runs these cases
-        nk = int(rng.choice([4, 8, 12, 16, 20, 24, 40, 60]))
+        # rows a multiple of 16 bytes: the LDS-DMA flavour of the march kernel, not the plain one,
+        # then runs these cases -- level counts that fill the cell waves and ragged ones
+        nk = int(rng.choice([1, 3, 4, 5, 7, 8, 12, 13, 16, 20, 23, 24, 27, 31, 35, 40, 45, 57, 60, 61, 70, 80]))
         kde, kme = nk + 1, nk + 1 + int(rng.integers(0, 3))
         ime += (-(ime - ims + 1)) % 4
     # tile: the whole domain, or a random sub-tile (as an OpenMP tile / slab would be)

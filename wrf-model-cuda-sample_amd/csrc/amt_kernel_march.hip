@@ -510,7 +510,11 @@ __device__ __forceinline__ void amt_lds_barrier()
 
 // XD: how many MORE input rows ride the DMA when LDS allows (fp32, or fp64 with nk <= ~44):
 //   0: t_1, v   1: + v_1 (row j+2)   2: + u (row j+1, with its i+1 halo)   3: + u_1  -> no global load left in P1
-template <typename T, int KPT, int XD>
+// FULL: nk is a multiple of KPT.  Otherwise the last cell wave owns fewer real levels; its missing
+// ones are VIRTUAL: they load the wave's last real level again (addresses clamped, wave-uniform),
+// compute on the duplicate and are never stored, so that the code stays free of per-level branches
+// (which would break the load batching) -- the LDS level buffers then hold nkr = waves*KPT rows.
+template <typename T, int KPT, int XD, bool FULL>
 __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_march_dma_kernel(const AmtParams<T> p, const AmtMarchGrid g)
 {
     extern __shared__ __align__(16) unsigned char amt_smem[];
@@ -525,19 +529,20 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
     // only ever reads its OWN slots after barrier 2, so the next row's P1 may overwrite them
     // without another barrier; the value it needs from the wave above is rebuilt from its own
     // last increment, kept in a register (the same subtraction the column wave performs).
-    T *AB = reinterpret_cast<T *>(amt_smem);      // [nk][64]
-    T *T1 = AB + (size_t)nk * 64;                 // [2][nk][64] t_1 rows (buffer = row parity)
-    T *V  = T1 + (size_t)2 * nk * 64;             // [nk][64]   v of row j+1
-    T *TH = V + (size_t)nk * 64;                  // [2][nk][2] i halo of the t_1 rows: left, right
-    T *V1 = TH + (size_t)4 * nk;                  // [nk][64]   v_1 of row j+1            (XD >= 1)
-    T *U  = V1 + (XD >= 1 ? (size_t)nk * 64 : 0); // [nk][64]   u of row j                (XD >= 2)
-    T *U1 = U + (XD >= 2 ? (size_t)nk * 64 : 0);  // [nk][64]   u_1 of row j              (XD >= 3)
-    T *UH = U1 + (XD >= 3 ? (size_t)nk * 64 : 0); // [2][nk]    element i+64 of the u / u_1 rows (XD >= 2)
-    T *D2 = UH + (XD >= 2 ? (size_t)2 * nk : 0);  // [N2D][66]  2-D inputs of the current row
+    const int nkr = FULL ? nk : ((int)(blockDim.x >> 6) - 1) * KPT;   // level rows of the LDS buffers
+    T *AB = reinterpret_cast<T *>(amt_smem);      // [nkr][64]
+    T *T1 = AB + (size_t)nkr * 64;                // [2][nkr][64] t_1 rows (buffer = row parity)
+    T *V  = T1 + (size_t)2 * nkr * 64;            // [nkr][64]   v of row j+1
+    T *TH = V + (size_t)nkr * 64;                 // [2][nkr][2] i halo of the t_1 rows: left, right
+    T *V1 = TH + (size_t)4 * nkr;                 // [nkr][64]   v_1 of row j+1            (XD >= 1)
+    T *U  = V1 + (XD >= 1 ? (size_t)nkr * 64 : 0); // [nkr][64]  u of row j                (XD >= 2)
+    T *U1 = U + (XD >= 2 ? (size_t)nkr * 64 : 0); // [nkr][64]   u_1 of row j              (XD >= 3)
+    T *UH = U1 + (XD >= 3 ? (size_t)nkr * 64 : 0); // [2][nkr]   element i+64 of the u / u_1 rows (XD >= 2)
+    T *D2 = UH + (XD >= 2 ? (size_t)2 * nkr : 0); // [N2D][66]  2-D inputs of the current row
     T *DM = D2 + (size_t)N2D * TW;                // [64]
-    T *S1 = DM + 64;                              // dnw | fnm | fnp | rdnw
-    const T *s_dnw = S1, *s_fnm = S1 + nk, *s_fnp = S1 + 2 * nk, *s_rdnw = S1 + 3 * nk;
-    const int t1buf = nk * 64, thbuf = nk * 2;
+    T *S1 = DM + 64;                              // dnw | fnm | fnp | rdnw, nkr entries each
+    const T *s_dnw = S1, *s_fnm = S1 + nkr, *s_fnp = S1 + 2 * nkr, *s_rdnw = S1 + 3 * nkr;
+    const int t1buf = nkr * 64, thbuf = nkr * 2;
 
     const int lane = threadIdx.x & 63;
     const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -555,10 +560,10 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
     const int tile = g.tile_lo + lid % g.ntile_i;
     const int jblk = lid / g.ntile_i;
 
-    for (int e = threadIdx.x; e < 4 * nk; e += blockDim.x) {
-        const int which = e / nk, k = e % nk;
+    for (int e = threadIdx.x; e < 4 * nkr; e += blockDim.x) {
+        const int which = e / nkr, k = e % nkr;
         const T *src = which == 0 ? p.dnw : which == 1 ? p.fnm : which == 2 ? p.fnp : p.rdnw;
-        S1[e] = src[p.k1 + k];
+        S1[e] = src[p.k1 + (k < nk ? k : nk - 1)];
     }
 
     const int ii   = tile * 64 + lane;
@@ -669,6 +674,8 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
         // ===================== cell waves =====================
         const int kf = w * KPT;
         const bool has_above = (kf + KPT < nk);
+        const int nlev = FULL ? KPT : (nk - kf < KPT ? nk - kf : KPT);      // real levels of this wave (>= 1)
+        auto lv = [&](int m) { return FULL ? m : (m < nlev ? m : nlev - 1); };   // level a (virtual) slot loads
         const T rdx = p.rdx, rdy = p.rdy, dts = p.dts;
         const T hrdy = T(.5) * rdy, hrdx = T(.5) * rdx;
         const long e3 = (long)ja * js + (long)(p.k1 + kf) * idim + (long)tile * 64;
@@ -684,10 +691,14 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
         const bool dok = tile * 64 + (lane % LPL) * EPL < p.idim;            // chunk lies inside the memory row
         // copies levels [kf .. kf+KPT) of j row (ja + rows) of `src` (uniform base at row ja) to lds
         auto dma_rows = [&](const T *src, int rows, T *lds) {
-            const unsigned ro = dvo + (unsigned)rows * row3;                 // the row advance rides in the lane offset
 #pragma unroll
             for (int q = 0; q < KPT / LPI; ++q) {
-                const char *ub = reinterpret_cast<const char *>(src) + (size_t)(q * LPI) * lev;
+                const char *ub = reinterpret_cast<const char *>(src) + (FULL ? (size_t)(q * LPI) * lev : (size_t)0);
+                unsigned ro = dvo + (unsigned)rows * row3;                   // the row advance rides in the lane offset
+                if (!FULL) {                                                 // virtual levels read the last real one
+                    const int l = q * LPI + dl;
+                    ro = (unsigned)(l < nlev ? l : nlev - 1) * lev + (unsigned)(lane % LPL) * 16u + (unsigned)rows * row3;
+                }
                 if (dok)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
                                                      (__attribute__((address_space(3))) void *)(lds + (size_t)(kf + q * LPI) * 64),
@@ -704,7 +715,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
             const unsigned ro = hvo + (unsigned)rows * row3;
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
-                const char *ub = reinterpret_cast<const char *>(src - 1) + (size_t)m * lev;
+                const char *ub = reinterpret_cast<const char *>(src - 1) + (size_t)lv(m) * lev;
                 if (hok)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
                                                      (__attribute__((address_space(3))) void *)(lds + (size_t)(kf + m) * 2),
@@ -719,7 +730,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
             const unsigned ro = uvo + (unsigned)rows * row3;
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
-                const char *ub = reinterpret_cast<const char *>(src) + (size_t)m * lev;
+                const char *ub = reinterpret_cast<const char *>(src) + (size_t)lv(m) * lev;
                 if (uok)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
                                                      (__attribute__((address_space(3))) void *)(lds + (size_t)(kf + m)),
@@ -733,7 +744,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
             dma_halo(t1_b, r + 1, thdst);
             if (XD >= 1) dma_rows(v1_b, r + 1, V1);                          // v_1(j+1)
             if (XD >= 2) { dma_rows(u_b, r, U); dma_uhalo(u_b, r, UH); }     // u(j), u(i+64)
-            if (XD >= 3) { dma_rows(u1_b, r, U1); dma_uhalo(u1_b, r, UH + nk); }
+            if (XD >= 3) { dma_rows(u1_b, r, U1); dma_uhalo(u1_b, r, UH + nkr); }
         };
 
         T vfm[KPT], vft[KPT];
@@ -749,7 +760,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
             if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
-                const unsigned om = vo + (unsigned)m * lev;
+                const unsigned om = vo + (unsigned)lv(m) * lev;
                 if (act) {
                     const T vv = amt_ld(v_b, om);
                     vfm[m] = vv + muv_j * amt_ld(p.v_1 + e3, om) * mvx_j;
@@ -785,7 +796,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 const int ll = lane > 0 ? lane - 1 : 0, lr = lane < 63 ? lane + 1 : 63;
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    const unsigned om = o3 + (unsigned)m * lev;
+                    const unsigned om = o3 + (unsigned)lv(m) * lev;
                     const int K = kf + m;
                     T v1n, uu, uup, u1, u1p;
                     if (XD >= 1) v1n = V1[K * 64 + lane]; else v1n = amt_ld(v1n_b, om);
@@ -797,7 +808,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                     if (XD >= 3) {
                         u1 = U1[K * 64 + lane];
                         const T up_in = U1[K * 64 + lr];
-                        u1p = lane == 63 ? UH[nk + K] : up_in;
+                        u1p = lane == 63 ? UH[nkr + K] : up_in;
                     } else { u1 = amt_ld_stream<2>(u1_b, om); u1p = amt_ld_stream<2>(u1_b + 1, om); }
                     const T vn = V[K * 64 + lane], t1n = T1n[K * 64 + lane];
                     const T t1c = T1c[K * 64 + lane];
@@ -827,7 +838,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 if (has_above) w1_above = amt_ld(ww1_b, o3 + (unsigned)KPT * lev);
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    const unsigned om = o3 + (unsigned)m * lev;
+                    const unsigned om = o3 + (unsigned)lv(m) * lev;
                     told[m] = amt_ld_stream<1>(t_b, om);
                     ftk[m] = amt_ld_stream<1>(ft_b, om);
                     w1[m] = amt_ld_stream<1>(ww1_b, om);
@@ -854,17 +865,19 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    const unsigned om = o3 + (unsigned)m * lev;
+                    const unsigned om = o3 + (unsigned)lv(m) * lev;
                     const int K = kf + m;
+                    const bool real = FULL || m < nlev;                // wave-uniform
                     const T wout = wwu - w1[m];
-                    amt_st_stream(ww_b, om, wout);
+                    if (real) amt_st_stream(ww_b, om, wout);
                     T wd_n = T(0);
                     const T wwu_n = (m + 1 < KPT) ? AB[(m + 1 < KPT ? K + 1 : K) * 64 + lane] : wwu - inc_last;
                     if (m + 1 < KPT) wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
                     else if (has_above) wd_n = (wwu_n - w1_above) * tw_above;
-                    amt_st_stream(tave_b, om, told[m]);
+                    if (!FULL && K + 1 >= nk) wd_n = T(0);               // wdtn(kde) = 0, :221
+                    if (real) amt_st_stream(tave_b, om, told[m]);
                     const T tb = told[m] + msfty * dts * ftk[m];
-                    amt_st_stream(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));
+                    if (real) amt_st_stream(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));
                     wwu = wwu_n; wd_k = wd_n;
                 }
             }
@@ -878,8 +891,10 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
 
 // Levels per cell wave.  Workgroup size (cell waves + the column wave) is bounded by the
 // kernel's __launch_bounds__: 16 waves (KPT < 8), 11 waves (KPT 8..10), 5 waves (KPT 15).
-// Smallest KPT that fits wins (most waves to hide latency, fewest registers per lane); a KPT
-// that divides nk is preferred (no level guards).
+// Smallest KPT that fits wins (most waves to hide latency, fewest registers per lane).  First
+// choice is a KPT the LDS-DMA flavour takes (whole DMA instructions per wave: a multiple of 2 in
+// fp64, of 4 in fp32); nk need not be a multiple of it (virtual levels).  fp64 keeps ~9 values per
+// level live and spills beyond KPT 4, so there the plain kernel's first fit is as good as it gets.
 template <typename T> static int amt_march_kpt(int nk)
 {
     static const int cand[] = {2, 4, 5, 6, 8, 10, 15};
@@ -887,11 +902,13 @@ template <typename T> static int amt_march_kpt(int nk)
     const int forced = amt_env_int("AMT_MARCH_KPT", 0);
     for (int k : cand)
         if (k == forced && (nk + k - 1) / k <= maxc(k)) return k;
+    constexpr int LPI = sizeof(T) == 8 ? 2 : 4;                        // levels per DMA instruction
+    for (int k : cand)
+        if ((nk + k - 1) / k <= maxc(k) && k % LPI == 0 && (sizeof(T) == 4 || k <= 4)) return k;
     int first_fit = 0;
     for (int k : cand) {
         if ((nk + k - 1) / k > maxc(k)) continue;
         if (!first_fit) first_fit = k;
-        // fp64 keeps ~9 values per level live: beyond KPT 4 it spills, so take the first fit
         if (nk % k == 0 && k <= 2 * first_fit && (sizeof(T) == 4 || k <= 4)) return k;
     }
     return first_fit;
@@ -967,43 +984,44 @@ static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &
     return hipGetLastError();
 }
 
-template <typename T> static size_t amt_march_dma_lds(int nk, int xd)
+template <typename T> static size_t amt_march_dma_lds(int nk, int kpt, int xd)
 {
-    // AB, T1[2], V (+ V1, U, U1): [nk][64]; TH [2][nk][2] (+ UH [2][nk]); D2 [7][66]; DM [64]; S1 [4][nk]
-    return ((size_t)(4 + xd) * nk * 64 + (size_t)4 * nk + (xd >= 2 ? (size_t)2 * nk : 0)
-            + AMT_N2D * AMT_TW + 64 + 4 * (size_t)nk) * sizeof(T);
+    // AB, T1[2], V (+ V1, U, U1): [nkr][64]; TH [2][nkr][2] (+ UH [2][nkr]); D2 [7][66]; DM [64]; S1 [4][nkr]
+    const size_t nkr = (size_t)((nk + kpt - 1) / kpt) * kpt;      // nk rounded up to whole cell waves
+    return ((size_t)(4 + xd) * nkr * 64 + (size_t)4 * nkr + (xd >= 2 ? (size_t)2 * nkr : 0)
+            + AMT_N2D * AMT_TW + 64 + 4 * nkr) * sizeof(T);
 }
 
 template <typename T, int KPT>
 static bool amt_march_dma_ok(const AmtParams<T> &p)
 {
     constexpr int EPL = 16 / (int)sizeof(T), LPI = 64 / (64 / EPL);
-    if (KPT % LPI != 0 || p.nk % KPT != 0) return false;
+    if (KPT % LPI != 0) return false;
     if (p.idim % EPL != 0) return false;
     if ((reinterpret_cast<uintptr_t>(p.t_1) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.v_1)
          | reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.u_1)) & 15u) return false;
-    if (amt_march_dma_lds<T>(p.nk, 0) > 160 * 1024) return false;
+    if (amt_march_dma_lds<T>(p.nk, KPT, 0) > 160 * 1024) return false;
     return amt_env_int("AMT_MARCH_DMA", 1) != 0;
 }
 
-template <typename T, int KPT, int XD>
+template <typename T, int KPT, int XD, bool FULL>
 static hipError_t amt_march_launch_dma_xd(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g)
 {
-    const size_t lds = amt_march_dma_lds<T>(p.nk, XD);
-    const int nw = p.nk / KPT + 1;
+    const size_t lds = amt_march_dma_lds<T>(p.nk, KPT, XD);
+    const int nw = (p.nk + KPT - 1) / KPT + 1;
     if (lds > 64 * 1024) {
         static thread_local size_t granted[64] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
         const int slot = (dev >= 0 && dev < 64) ? dev : 0;
         if (lds > granted[slot] || slot != dev) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_dma_kernel<T, KPT, XD>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_march_dma_kernel<T, KPT, XD, FULL>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             granted[slot] = lds;
         }
     }
-    hipLaunchKernelGGL((amt_march_dma_kernel<T, KPT, XD>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
+    hipLaunchKernelGGL((amt_march_dma_kernel<T, KPT, XD, FULL>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
     return hipGetLastError();
 }
 
@@ -1017,19 +1035,20 @@ static hipError_t amt_march_launch_dma(hipStream_t stream, const AmtParams<T> &p
         // live VGPRs and spill (NK 40: 11.86 vs 11.26 ms; NK 60: v_1 alone 15.77 vs 15.72 without), at
         // KPT 2 (NK <= 30) they fit and pay (NK 20: 5.62 vs 5.82 ms)
         int xd = 3;
-        while (xd > 0 && amt_march_dma_lds<T>(p.nk, xd) > 160 * 1024) --xd;
+        while (xd > 0 && amt_march_dma_lds<T>(p.nk, KPT, xd) > 160 * 1024) --xd;
         if (xd == 2) xd = 1;
         if (sizeof(T) == 8 && !(xd == 3 && KPT <= 2)) xd = 0;
         const int cap = amt_env_int("AMT_MARCH_XD", -1);
         if (cap >= 0) {
             xd = cap > 3 ? 3 : cap;
-            while (xd > 0 && amt_march_dma_lds<T>(p.nk, xd) > 160 * 1024) --xd;
+            while (xd > 0 && amt_march_dma_lds<T>(p.nk, KPT, xd) > 160 * 1024) --xd;
         }
+        const bool full = p.nk % KPT == 0;
         switch (xd) {
-        case 3:  return amt_march_launch_dma_xd<T, KPT, 3>(stream, p, g);
-        case 2:  return amt_march_launch_dma_xd<T, KPT, 2>(stream, p, g);
-        case 1:  return amt_march_launch_dma_xd<T, KPT, 1>(stream, p, g);
-        default: return amt_march_launch_dma_xd<T, KPT, 0>(stream, p, g);
+        case 3:  return full ? amt_march_launch_dma_xd<T, KPT, 3, true>(stream, p, g) : amt_march_launch_dma_xd<T, KPT, 3, false>(stream, p, g);
+        case 2:  return full ? amt_march_launch_dma_xd<T, KPT, 2, true>(stream, p, g) : amt_march_launch_dma_xd<T, KPT, 2, false>(stream, p, g);
+        case 1:  return full ? amt_march_launch_dma_xd<T, KPT, 1, true>(stream, p, g) : amt_march_launch_dma_xd<T, KPT, 1, false>(stream, p, g);
+        default: return full ? amt_march_launch_dma_xd<T, KPT, 0, true>(stream, p, g) : amt_march_launch_dma_xd<T, KPT, 0, false>(stream, p, g);
         }
     } else {
         return hipErrorNotSupported;
