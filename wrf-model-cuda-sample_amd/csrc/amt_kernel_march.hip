@@ -122,15 +122,19 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
     extern __shared__ __align__(16) unsigned char amt_smem[];
     const int nk = p.nk;
     constexpr int TW = AMT_TW, N2D = AMT_N2D;
-    T *AP = reinterpret_cast<T *>(amt_smem);      // [nk][64]   dnw(k)*dvdxi(i,k)  (the terms of dmdt)
-    T *B  = AP + (size_t)nk * 64;                 // [nk][64]   ww increments, then ww(k+1) of the recurrence
-    T *T1 = B + (size_t)nk * 64;                  // [2][nk][66] t_1 of row j / row j+1 (+ i halo)
-    T *D2 = T1 + (size_t)2 * nk * TW;             // [2][N2D][66] 2-D inputs of row j / row j+1
+    // level rows of the LDS buffers: nk, or whole cell waves when nk % KPT != 0 (the last wave's
+    // missing levels are virtual: clamped loads of its last real level, never stored -- see the
+    // LDS-DMA flavour below)
+    const int nkr = FULL ? nk : ((int)(blockDim.x >> 6) - 1) * KPT;
+    T *AP = reinterpret_cast<T *>(amt_smem);      // [nkr][64]  dnw(k)*dvdxi(i,k)  (the terms of dmdt)
+    T *B  = AP + (size_t)nkr * 64;                // [nkr][64]  ww increments, then ww(k+1) of the recurrence
+    T *T1 = B + (size_t)nkr * 64;                 // [2][nkr][66] t_1 of row j / row j+1 (+ i halo)
+    T *D2 = T1 + (size_t)2 * nkr * TW;            // [2][N2D][66] 2-D inputs of row j / row j+1
     T *DM = D2 + (size_t)2 * N2D * TW;            // [64] dmdt of the row
     T *W0 = DM + 64;                              // [64] incoming ww(i,1,j) of the row
-    T *S1 = W0 + 64;                              // dnw | fnm | fnp | rdnw, nk entries each
-    const T *s_dnw = S1, *s_fnm = S1 + nk, *s_fnp = S1 + 2 * nk, *s_rdnw = S1 + 3 * nk;
-    const int t1buf = nk * TW, d2buf = N2D * TW;
+    T *S1 = W0 + 64;                              // dnw | fnm | fnp | rdnw, nkr entries each
+    const T *s_dnw = S1, *s_fnm = S1 + nkr, *s_fnp = S1 + 2 * nkr, *s_rdnw = S1 + 3 * nkr;
+    const int t1buf = nkr * TW, d2buf = N2D * TW;
 
     const int lane = threadIdx.x & 63;
     const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
@@ -162,10 +166,10 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
     const int tile = g.tile_lo + lid % g.ntile_i;
     const int jblk = lid / g.ntile_i;
 
-    for (int e = threadIdx.x; e < 4 * nk; e += blockDim.x) {
-        const int which = e / nk, k = e % nk;
+    for (int e = threadIdx.x; e < 4 * nkr; e += blockDim.x) {
+        const int which = e / nkr, k = e % nkr;
         const T *src = which == 0 ? p.dnw : which == 1 ? p.fnm : which == 2 ? p.fnp : p.rdnw;
-        S1[e] = src[p.k1 + k];
+        S1[e] = src[p.k1 + (k < nk ? k : nk - 1)];
     }
 
     const int ii   = tile * 64 + lane;
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
         // =====================================================================
         const int kf   = w * KPT;                      // my levels: zero-based kf .. kf+nlev-1
         const int nlev = FULL ? KPT : ((nk - kf < KPT) ? (nk - kf) : KPT);
+        auto lv = [&](int m) { return FULL ? m : (m < nlev ? m : nlev - 1); };   // level a (virtual) slot loads
         const bool has_above = (kf + KPT < nk);        // zero-based level kf+KPT exists
         const T rdx = p.rdx, rdy = p.rdy, dts = p.dts;
         const T hrdy = T(.5) * rdy, hrdx = T(.5) * rdx;
@@ -328,8 +333,8 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
             if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
-                if (FULL || m < nlev) {
-                    const unsigned om = vo + (unsigned)m * lev;
+                {
+                    const unsigned om = vo + (unsigned)lv(m) * lev;
                     const int K = kf + m;
                     if (t1ok) {
                         const T tc = amt_ld(p.t_1 + e3, om);
@@ -360,14 +365,12 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
             if (t1ok && !act) {                                      // the (at most two) columns beside the window
 #pragma unroll
                 for (int m = 0; m < KPT; ++m)
-                    if (FULL || m < nlev)
-                        T1n[(kf + m) * TW + 1 + lane] = amt_ld(t1n_b, o3 + (unsigned)m * lev);
+                    T1n[(kf + m) * TW + 1 + lane] = amt_ld(t1n_b, o3 + (unsigned)lv(m) * lev);
             }
             if (edge) {
 #pragma unroll
                 for (int m = 0; m < KPT; ++m)
-                    if (FULL || m < nlev)
-                        T1n[(kf + m) * TW + ehalo] = amt_ld(t1n_b - 1, o3 + (unsigned)m * lev + eoff);
+                    T1n[(kf + m) * TW + ehalo] = amt_ld(t1n_b - 1, o3 + (unsigned)lv(m) * lev + eoff);
             }
             if (act) {
                 const T msftx = D2c[0 * TW + 1 + lane];
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 }
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    if (FULL || m < nlev) {
-                        const unsigned om = o3 + (unsigned)m * lev;
+                    {
+                        const unsigned om = o3 + (unsigned)lv(m) * lev;
                         const int K = kf + m;
                         const T vn = amt_ld(vn_b, om), v1n = amt_ld(v1n_b, om);
                         const T t1n = amt_ld(t1n_b, om);                       // t_1(i,k,j+1)
@@ -422,8 +425,8 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 if (has_above) w1_above = amt_ld(ww1_b, o3 + (unsigned)KPT * lev);
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    if (FULL || m < nlev) {
-                        const unsigned om = o3 + (unsigned)m * lev;
+                    {
+                        const unsigned om = o3 + (unsigned)lv(m) * lev;
                         told[m] = amt_ld_stream<1>(t_b, om);
                         ftk[m] = amt_ld_stream<1>(ft_b, om);
                         w1[m] = amt_ld_stream<1>(ww1_b, om);
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 const T dmdt = DM[lane];
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    if (FULL || m < nlev) {
+                    {
                         const int K = kf + m;
                         B[K * 64 + lane] = s_dnw[K] * (dmdt + dv[m] + mu_tend) / msfty;   // :161
                     }
@@ -457,22 +460,24 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];   // wdtn(i,1) = 0 (:220)
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    if (FULL || m < nlev) {
-                        const unsigned om = o3 + (unsigned)m * lev;
+                    {
+                        const unsigned om = o3 + (unsigned)lv(m) * lev;
                         const int K = kf + m;
+                        const bool real = FULL || m < nlev;          // wave-uniform
                         const T wout = wwu - w1[m];                  // :170
-                        amt_st_stream(ww_b, om, wout);
+                        if (real) amt_st_stream(ww_b, om, wout);
                         // wdtn at level K+1 (:221,:227)
                         T wd_n = T(0);
                         const T wwu_n = B[K * 64 + lane];
                         if (m + 1 < KPT) {
-                            if (FULL || m + 1 < nlev) wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
+                            wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
+                            if (!FULL && K + 1 >= nk) wd_n = T(0);                            // wdtn(kde) = 0, :221
                         } else if (has_above) {
                             wd_n = (wwu_n - w1_above) * tw_above;
                         }
-                        amt_st_stream(tave_b, om, told[m]);                                          // :211
+                        if (real) amt_st_stream(tave_b, om, told[m]);                                // :211
                         const T tb = told[m] + msfty * dts * ftk[m];                          // :212
-                        amt_st_stream(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));   // :237-246
+                        if (real) amt_st_stream(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));   // :237-246
                         wwu = wwu_n; wd_k = wd_n;
                     }
                 }
@@ -914,9 +919,10 @@ template <typename T> static int amt_march_kpt(int nk)
     return first_fit;
 }
 
-template <typename T> static size_t amt_march_lds(int nk)
+template <typename T> static size_t amt_march_lds(int nk, int kpt)
 {
-    return ((size_t)2 * nk * 64 + (size_t)2 * nk * AMT_TW + 2 * AMT_N2D * AMT_TW + 128 + 4 * (size_t)nk) * sizeof(T);
+    const size_t nkr = (size_t)((nk + kpt - 1) / kpt) * kpt;      // nk rounded up to whole cell waves
+    return ((size_t)2 * nkr * 64 + (size_t)2 * nkr * AMT_TW + 2 * AMT_N2D * AMT_TW + 128 + 4 * nkr) * sizeof(T);
 }
 
 template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
@@ -928,8 +934,8 @@ template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
 
 template <typename T> bool amt_march_supported(const AmtParams<T> &p)
 {
-    return p.nk >= 1 && amt_march_kpt<T>(p.nk) != 0 && amt_march_lds<T>(p.nk) <= 160 * 1024
-           && amt_march_max_rows(p) >= 1;
+    const int kpt = p.nk >= 1 ? amt_march_kpt<T>(p.nk) : 0;
+    return kpt != 0 && amt_march_lds<T>(p.nk, kpt) <= 160 * 1024 && amt_march_max_rows(p) >= 1;
 }
 
 template <typename T, int KPT, bool FULL>
@@ -1092,7 +1098,7 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
             (void)hipGetLastError();
             slots = cus;
         }
-        const size_t lds_need = amt_march_lds<T>(p.nk);
+        const size_t lds_need = amt_march_lds<T>(p.nk, kpt);
         const int per_cu = (int)((160u * 1024u) / (lds_need ? lds_need : 1));     // LDS is what bounds residency
         const long sl = (long)slots * (per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu);
         double best = 1e300;
@@ -1111,7 +1117,7 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
     g.jrows = jrows;
     g.njblk = (nj + jrows - 1) / jrows;
     g.nwg = g.ntile_i * g.njblk;
-    const size_t lds = amt_march_lds<T>(p.nk);
+    const size_t lds = amt_march_lds<T>(p.nk, kpt);
     switch (kpt) {
     case 2:  return amt_march_launch_kpt<T, 2>(stream, p, g, lds);
     case 4:  return amt_march_launch_kpt<T, 4>(stream, p, g, lds);
