@@ -894,35 +894,58 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
 // launch
 // ---------------------------------------------------------------------------
 
-// Levels per cell wave.  Workgroup size (cell waves + the column wave) is bounded by the
-// kernel's __launch_bounds__: 16 waves (KPT < 8), 11 waves (KPT 8..10), 5 waves (KPT 15).
-// Smallest KPT that fits wins (most waves to hide latency, fewest registers per lane).  First
-// choice is a KPT the LDS-DMA flavour takes (whole DMA instructions per wave: a multiple of 2 in
-// fp64, of 4 in fp32); nk need not be a multiple of it (virtual levels).  fp64 keeps ~9 values per
-// level live and spills beyond KPT 4, so there the plain kernel's first fit is as good as it gets.
-template <typename T> static int amt_march_kpt(int nk)
-{
-    static const int cand[] = {2, 4, 5, 6, 8, 10, 15};
-    auto maxc = [](int k) { return k >= 15 ? 4 : k >= 8 ? 10 : 15; };  // cell waves
-    const int forced = amt_env_int("AMT_MARCH_KPT", 0);
-    for (int k : cand)
-        if (k == forced && (nk + k - 1) / k <= maxc(k)) return k;
-    constexpr int LPI = sizeof(T) == 8 ? 2 : 4;                        // levels per DMA instruction
-    for (int k : cand)
-        if ((nk + k - 1) / k <= maxc(k) && k % LPI == 0 && (sizeof(T) == 4 || k <= 4)) return k;
-    int first_fit = 0;
-    for (int k : cand) {
-        if ((nk + k - 1) / k > maxc(k)) continue;
-        if (!first_fit) first_fit = k;
-        if (nk % k == 0 && k <= 2 * first_fit && (sizeof(T) == 4 || k <= 4)) return k;
-    }
-    return first_fit;
-}
-
 template <typename T> static size_t amt_march_lds(int nk, int kpt)
 {
     const size_t nkr = (size_t)((nk + kpt - 1) / kpt) * kpt;      // nk rounded up to whole cell waves
     return ((size_t)2 * nkr * 64 + (size_t)2 * nkr * AMT_TW + 2 * AMT_N2D * AMT_TW + 128 + 4 * nkr) * sizeof(T);
+}
+
+template <typename T> static size_t amt_march_dma_lds(int nk, int kpt, int xd)
+{
+    // AB, T1[2], V (+ V1, U, U1): [nkr][64]; TH [2][nkr][2] (+ UH [2][nkr]); D2 [7][66]; DM [64]; S1 [4][nkr]
+    const size_t nkr = (size_t)((nk + kpt - 1) / kpt) * kpt;
+    return ((size_t)(4 + xd) * nkr * 64 + (size_t)4 * nkr + (xd >= 2 ? (size_t)2 * nkr : 0)
+            + AMT_N2D * AMT_TW + 64 + 4 * nkr) * sizeof(T);
+}
+
+// The LDS-DMA flavour moves 16-byte chunks: rows a multiple of 16 bytes, 16-byte aligned bases.
+template <typename T> static bool amt_march_dma_layout_ok(const AmtParams<T> &p)
+{
+    constexpr int EPL = 16 / (int)sizeof(T);
+    if (p.idim % EPL != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(p.t_1) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.v_1)
+         | reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.u_1)) & 15u) return false;
+    return amt_env_int("AMT_MARCH_DMA", 1) != 0;
+}
+
+// Levels per cell wave.  Workgroup size (cell waves + the column wave) is bounded by the
+// kernel's __launch_bounds__: 16 waves (KPT < 8), 11 waves (KPT 8..10), 5 waves (KPT 15), and
+// the level buffers must fit the 160 KB of LDS.  Preference, measured (profiles/ab_libs.py):
+// the smallest KPT the LDS-DMA flavour takes (whole DMA instructions per wave: a multiple of 2 in
+// fp64, of 4 in fp32) -- most waves to hide latency, fewest registers per lane; nk need not be a
+// multiple of it (virtual levels).  fp64 keeps ~9 values per level live: KPT 5 and 6 spill inside
+// the 128-VGPR budget of a 16-wave workgroup, KPT 8 has the 170 of an 11-wave one and beats them
+// (NK 64: 5.71 vs 6.11 ms; NK 72: 6.16 vs 6.39 ms per 4096 x NK x 1024 sweep).
+template <typename T> static int amt_march_kpt(const AmtParams<T> &p)
+{
+    const int nk = p.nk;
+    if (nk < 1) return 0;
+    constexpr int LPI = sizeof(T) == 8 ? 2 : 4;                        // levels per DMA instruction
+    static const int pref64[] = {2, 4, 8, 6, 5, 10, 15}, pref32[] = {4, 8, 5, 6, 10, 15, 2};
+    const int *pref = sizeof(T) == 8 ? pref64 : pref32;
+    auto maxc = [](int k) { return k >= 15 ? 4 : k >= 8 ? 10 : 15; };  // cell waves
+    const bool dma_layout = amt_march_dma_layout_ok(p);
+    auto feasible = [&](int k) {
+        if ((nk + k - 1) / k > maxc(k)) return false;
+        if (dma_layout && k % LPI == 0 && amt_march_dma_lds<T>(nk, k, 0) <= 160 * 1024) return true;
+        return amt_march_lds<T>(nk, k) <= 160 * 1024;
+    };
+    const int forced = amt_env_int("AMT_MARCH_KPT", 0);
+    for (int i = 0; i < 7; ++i)
+        if (pref[i] == forced && feasible(forced)) return forced;
+    for (int i = 0; i < 7; ++i)
+        if (feasible(pref[i])) return pref[i];
+    return 0;
 }
 
 template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
@@ -934,8 +957,7 @@ template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
 
 template <typename T> bool amt_march_supported(const AmtParams<T> &p)
 {
-    const int kpt = p.nk >= 1 ? amt_march_kpt<T>(p.nk) : 0;
-    return kpt != 0 && amt_march_lds<T>(p.nk, kpt) <= 160 * 1024 && amt_march_max_rows(p) >= 1;
+    return amt_march_kpt<T>(p) != 0 && amt_march_max_rows(p) >= 1;
 }
 
 template <typename T, int KPT, bool FULL>
@@ -990,24 +1012,11 @@ static hipError_t amt_march_launch_full(hipStream_t stream, const AmtParams<T> &
     return hipGetLastError();
 }
 
-template <typename T> static size_t amt_march_dma_lds(int nk, int kpt, int xd)
-{
-    // AB, T1[2], V (+ V1, U, U1): [nkr][64]; TH [2][nkr][2] (+ UH [2][nkr]); D2 [7][66]; DM [64]; S1 [4][nkr]
-    const size_t nkr = (size_t)((nk + kpt - 1) / kpt) * kpt;      // nk rounded up to whole cell waves
-    return ((size_t)(4 + xd) * nkr * 64 + (size_t)4 * nkr + (xd >= 2 ? (size_t)2 * nkr : 0)
-            + AMT_N2D * AMT_TW + 64 + 4 * nkr) * sizeof(T);
-}
-
 template <typename T, int KPT>
 static bool amt_march_dma_ok(const AmtParams<T> &p)
 {
     constexpr int EPL = 16 / (int)sizeof(T), LPI = 64 / (64 / EPL);
-    if (KPT % LPI != 0) return false;
-    if (p.idim % EPL != 0) return false;
-    if ((reinterpret_cast<uintptr_t>(p.t_1) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.v_1)
-         | reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.u_1)) & 15u) return false;
-    if (amt_march_dma_lds<T>(p.nk, KPT, 0) > 160 * 1024) return false;
-    return amt_env_int("AMT_MARCH_DMA", 1) != 0;
+    return KPT % LPI == 0 && amt_march_dma_layout_ok(p) && amt_march_dma_lds<T>(p.nk, KPT, 0) <= 160 * 1024;
 }
 
 template <typename T, int KPT, int XD, bool FULL>
@@ -1075,7 +1084,7 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
 {
     const int ni = p.i1 - p.i0 + 1, nj = p.j1 - p.j0 + 1;
     if (ni <= 0 || nj <= 0) return hipSuccess;
-    const int kpt = amt_march_kpt<T>(p.nk);
+    const int kpt = amt_march_kpt<T>(p);
     if (kpt == 0) return hipErrorNotSupported;
     AmtMarchGrid g;
     g.stamps = nullptr;
