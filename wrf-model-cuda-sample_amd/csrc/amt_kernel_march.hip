@@ -21,14 +21,16 @@
 //      -- barrier 1 --
 //      column wave  dmdt = sum_k AP[k] in the Fortran's sequential k order -> DM[lane]
 //      -- barrier 2 --
-//      cell waves   B[k][lane] = dnw(k)*(dmdt+dvdxi(k)+mu_tend)/msfty  (:161, one divide
-//                   per cell); column wave: the 2-D mass update (:151-157)
+//      cell waves   AP[k][lane] <- dnw(k)*(dmdt+dvdxi(k)+mu_tend)/msfty  (:161, one divide
+//                   per cell, own slots); column wave: the 2-D mass update (:151-157)
 //      -- barrier 3 --
-//      column wave  ww(k+1) = ww(k) - B[k], sequential, written back into B  (:161)
+//      column wave  AP[k] <- ww(k); ww(k+1) = ww(k) - AP[k], sequential  (:161)
 //      -- barrier 4 --
 //      cell waves   ww - ww_1 (:170), wdtn (:220-227), theta update (:211-212, :237-246)
 //    A column's chains are summed exactly once, in order: bit-exact and no redundant LDS
 //    traffic (an earlier version let every wave redo both chains: LDS-bandwidth bound).
+//  * Level counts that do not fill the cell waves: the last wave's missing levels are virtual
+//    (clamped loads of its last real level, no stores) -- no per-level branches.
 //  * Expressions keep the Fortran association; built with -ffp-contract=off.
 //  * Two flavours of the same kernel: amt_march_kernel (general) and amt_march_dma_kernel, which
 //    additionally prefetches the next row's t_1 and v through LDS-DMA (see its header below).
@@ -126,13 +128,16 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
     // missing levels are virtual: clamped loads of its last real level, never stored -- see the
     // LDS-DMA flavour below)
     const int nkr = FULL ? nk : ((int)(blockDim.x >> 6) - 1) * KPT;
-    T *AP = reinterpret_cast<T *>(amt_smem);      // [nkr][64]  dnw(k)*dvdxi(i,k)  (the terms of dmdt)
-    T *B  = AP + (size_t)nkr * 64;                // [nkr][64]  ww increments, then ww(k+1) of the recurrence
-    T *T1 = B + (size_t)nkr * 64;                 // [2][nkr][66] t_1 of row j / row j+1 (+ i halo)
+    // AP[k][lane] goes through three lives per row: dnw(k)*dvdxi(i,k), the term of dmdt (P1 ..
+    // barrier 2); the ww increment of level k (barrier 2 .. 3); ww(k) of the recurrence :161
+    // (barrier 4 .. P3).  A cell wave only ever reads its OWN slots after barrier 2, so the next
+    // row's P1 may overwrite them without another barrier; the ww of the level above its last one
+    // is rebuilt from its own last increment (the same subtraction the column wave performs).
+    T *AP = reinterpret_cast<T *>(amt_smem);      // [nkr][64]
+    T *T1 = AP + (size_t)nkr * 64;                // [2][nkr][66] t_1 of row j / row j+1 (+ i halo)
     T *D2 = T1 + (size_t)2 * nkr * TW;            // [2][N2D][66] 2-D inputs of row j / row j+1
     T *DM = D2 + (size_t)2 * N2D * TW;            // [64] dmdt of the row
-    T *W0 = DM + 64;                              // [64] incoming ww(i,1,j) of the row
-    T *S1 = W0 + 64;                              // dnw | fnm | fnp | rdnw, nkr entries each
+    T *S1 = DM + 64;                              // dnw | fnm | fnp | rdnw, nkr entries each
     const T *s_dnw = S1, *s_fnm = S1 + nkr, *s_fnp = S1 + 2 * nkr, *s_rdnw = S1 + 3 * nkr;
     const int t1buf = nkr * TW, d2buf = N2D * TW;
 
@@ -265,9 +270,8 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 for (; k < nk; ++k) dmdt = dmdt + AP[k * 64 + lane];
             }
             DM[lane] = dmdt;
-            W0[lane] = ww1in;
             stamp(2);
-            __syncthreads();                                     // 2: DM, W0 published
+            __syncthreads();                                     // 2: DM published
             stamp(3);
             if (act) {                                           // :151-157
                 const T mu_new = mu_old + dts * (dmdt + mu_tend);
@@ -284,19 +288,19 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 }
             }
             stamp(4);
-            __syncthreads();                                     // 3: B (increments) complete
+            __syncthreads();                                     // 3: AP holds the increments
             stamp(5);
-            {                                                    // :161, sequential in k; B[k] <- ww(k+1)
+            {                                                    // :161, sequential in k; AP[k] <- ww(k), the value BEFORE increment k
                 T wwu = ww1in;
                 int k = 0;
                 for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
                     T b[AMT_CHAIN];
 #pragma unroll
-                    for (int q = 0; q < AMT_CHAIN; ++q) b[q] = B[(k + q) * 64 + lane];
+                    for (int q = 0; q < AMT_CHAIN; ++q) b[q] = AP[(k + q) * 64 + lane];
 #pragma unroll
-                    for (int q = 0; q < AMT_CHAIN; ++q) { wwu = wwu - b[q]; B[(k + q) * 64 + lane] = wwu; }
+                    for (int q = 0; q < AMT_CHAIN; ++q) { AP[(k + q) * 64 + lane] = wwu; wwu = wwu - b[q]; }
                 }
-                for (; k < nk; ++k) { wwu = wwu - B[k * 64 + lane]; B[k * 64 + lane] = wwu; }
+                for (; k < nk; ++k) { const T bk = AP[k * 64 + lane]; AP[k * 64 + lane] = wwu; wwu = wwu - bk; }
             }
             stamp(6);
             __syncthreads();                                     // 4: ww of the recurrence published
@@ -434,29 +438,32 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 }
             }
             stamp(2);
-            __syncthreads();                                         // 2: DM, W0 published
+            __syncthreads();                                         // 2: DM published
             stamp(3);
+            T inc_last = T(0);                                      // my top level's increment (:161)
             if (act) {
                 const T dmdt = DM[lane];
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
                     {
                         const int K = kf + m;
-                        B[K * 64 + lane] = s_dnw[K] * (dmdt + dv[m] + mu_tend) / msfty;   // :161
+                        const T inc = s_dnw[K] * (dmdt + dv[m] + mu_tend) / msfty;   // :161
+                        AP[K * 64 + lane] = inc;
+                        if (m == KPT - 1) inc_last = inc;
                     }
                 }
             }
             stamp(4);
-            __syncthreads();                                         // 3: B (increments) complete
+            __syncthreads();                                         // 3: AP holds the increments
             stamp(5);
             // nothing to do while the column wave runs the ww recurrence
             stamp(6);
-            __syncthreads();                                         // 4: B[k] = ww(k+1) of the recurrence
+            __syncthreads();                                         // 4: AP[k] = ww(k) of the recurrence
             stamp(7);
 
             // ---------------- P3: vertical flux, theta ----------------
             if (act) {
-                T wwu = (kf == 0) ? W0[lane] : B[(kf > 0 ? kf - 1 : 0) * 64 + lane];   // ww of :161 at my first level
+                T wwu = AP[kf * 64 + lane];                          // ww of :161 at my first level
                 T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];   // wdtn(i,1) = 0 (:220)
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                         if (real) amt_st_stream(ww_b, om, wout);
                         // wdtn at level K+1 (:221,:227)
                         T wd_n = T(0);
-                        const T wwu_n = B[K * 64 + lane];
+                        const T wwu_n = (m + 1 < KPT) ? AP[(m + 1 < KPT ? K + 1 : K) * 64 + lane] : wwu - inc_last;
                         if (m + 1 < KPT) {
                             wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
                             if (!FULL && K + 1 >= nk) wd_n = T(0);                            // wdtn(kde) = 0, :221
@@ -482,9 +489,8 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                     }
                 }
             }
-            // No barrier here.  What the next row's P1 writes (AP, and the T1 buffer that was
-            // READ in this row's P1) is read by nobody after barrier 1 of this row; B and W0
-            // (read above) are next written after barrier 2 / barrier 1 of the next row.
+            // No barrier here.  What the next row's P1 writes (its own AP slots, and the T1 buffer
+            // that was READ in this row's P1) is read by no other wave before barrier 1 of the next row.
         }
     }
     if (STAMP && g.stamps && lane == 0) {
@@ -897,7 +903,8 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
 template <typename T> static size_t amt_march_lds(int nk, int kpt)
 {
     const size_t nkr = (size_t)((nk + kpt - 1) / kpt) * kpt;      // nk rounded up to whole cell waves
-    return ((size_t)2 * nkr * 64 + (size_t)2 * nkr * AMT_TW + 2 * AMT_N2D * AMT_TW + 128 + 4 * nkr) * sizeof(T);
+    // AP [nkr][64]; T1 [2][nkr][66]; D2 [2][7][66]; DM [64]; S1 [4][nkr]
+    return ((size_t)nkr * 64 + (size_t)2 * nkr * AMT_TW + 2 * AMT_N2D * AMT_TW + 64 + 4 * nkr) * sizeof(T);
 }
 
 template <typename T> static size_t amt_march_dma_lds(int nk, int kpt, int xd)
