@@ -337,20 +337,18 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
             if (act) { muv_j = amt_ld(p.muv + e2, vo); mvx_j = amt_ld(p.msfvx_inv + e2, vo); }
 #pragma unroll
             for (int m = 0; m < KPT; ++m) {
-                {
-                    const unsigned om = vo + (unsigned)lv(m) * lev;
-                    const int K = kf + m;
-                    if (t1ok) {
-                        const T tc = amt_ld(p.t_1 + e3, om);
-                        T1[K * TW + 1 + lane] = tc;
-                        if (act) {
-                            const T vv = amt_ld(p.v + e3, om);
-                            vfm[m] = vv + muv_j * amt_ld(p.v_1 + e3, om) * mvx_j;
-                            vft[m] = vv * (tc + amt_ld(p.t_1 + e3 - js, om));
-                        }
+                const unsigned om = vo + (unsigned)lv(m) * lev;
+                const int K = kf + m;
+                if (t1ok) {
+                    const T tc = amt_ld(p.t_1 + e3, om);
+                    T1[K * TW + 1 + lane] = tc;
+                    if (act) {
+                        const T vv = amt_ld(p.v + e3, om);
+                        vfm[m] = vv + muv_j * amt_ld(p.v_1 + e3, om) * mvx_j;
+                        vft[m] = vv * (tc + amt_ld(p.t_1 + e3 - js, om));
                     }
-                    if (edge) T1[K * TW + ehalo] = amt_ld(p.t_1 + e3 - 1, om + eoff);
                 }
+                if (edge) T1[K * TW + ehalo] = amt_ld(p.t_1 + e3 - 1, om + eoff);
             }
         }
         __syncthreads();                               // S1, T1[0], D2[0] staged
@@ -391,31 +389,29 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 }
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    {
-                        const unsigned om = o3 + (unsigned)lv(m) * lev;
-                        const int K = kf + m;
-                        const T vn = amt_ld(vn_b, om), v1n = amt_ld(v1n_b, om);
-                        const T t1n = amt_ld(t1n_b, om);                       // t_1(i,k,j+1)
-                        T1n[K * TW + 1 + lane] = t1n;
-                        const T uu = amt_ld(u_b, om), uup = amt_ld(u_b + 1, om);
-                        const T u1 = amt_ld(u1_b, om), u1p = amt_ld(u1_b + 1, om);
-                        const T t1c = T1c[K * TW + 1 + lane], t1l = T1c[K * TW + lane], t1r = T1c[K * TW + 2 + lane];
-                        // :142-146
-                        const T vfm_n = vn + muv_p * v1n * mvx_p;
-                        const T d = mm * ( rdy * (vfm_n - vfm[m])
-                                         + rdx * ( (uup + muu_ip * u1p / msfuy_ip)
-                                                 - (uu  + muu_i  * u1  / msfuy_i ) ));
-                        dv[m] = d;
-                        AP[K * 64 + lane] = s_dnw[K] * d;            // the term of :147
-                        // horizontal part of :237-245
-                        const T vft_n = vn * (t1n + t1c);
-                        hf[m] = msftx * ( hrdy * (vft_n - vft[m])
-                                        + hrdx * ( uup * (t1r + t1c) - uu * (t1c + t1l) ) );
-                        // fnm(k)*t_1(k) + fnp(k)*t_1(k-1) of :227 (unused for Fortran level 1)
-                        const T t1km1 = (K > 0) ? T1c[(K > 0 ? K - 1 : 0) * TW + 1 + lane] : T(0);
-                        tw[m] = s_fnm[K] * t1c + s_fnp[K] * t1km1;
-                        vfm[m] = vfm_n; vft[m] = vft_n;              // the faces of row j+1
-                    }
+                    const unsigned om = o3 + (unsigned)lv(m) * lev;
+                    const int K = kf + m;
+                    const T vn = amt_ld(vn_b, om), v1n = amt_ld(v1n_b, om);
+                    const T t1n = amt_ld(t1n_b, om);                       // t_1(i,k,j+1)
+                    T1n[K * TW + 1 + lane] = t1n;
+                    const T uu = amt_ld(u_b, om), uup = amt_ld(u_b + 1, om);
+                    const T u1 = amt_ld(u1_b, om), u1p = amt_ld(u1_b + 1, om);
+                    const T t1c = T1c[K * TW + 1 + lane], t1l = T1c[K * TW + lane], t1r = T1c[K * TW + 2 + lane];
+                    // :142-146
+                    const T vfm_n = vn + muv_p * v1n * mvx_p;
+                    const T d = mm * ( rdy * (vfm_n - vfm[m])
+                                     + rdx * ( (uup + muu_ip * u1p / msfuy_ip)
+                                             - (uu  + muu_i  * u1  / msfuy_i ) ));
+                    dv[m] = d;
+                    AP[K * 64 + lane] = s_dnw[K] * d;            // the term of :147
+                    // horizontal part of :237-245
+                    const T vft_n = vn * (t1n + t1c);
+                    hf[m] = msftx * ( hrdy * (vft_n - vft[m])
+                                    + hrdx * ( uup * (t1r + t1c) - uu * (t1c + t1l) ) );
+                    // fnm(k)*t_1(k) + fnp(k)*t_1(k-1) of :227 (unused for Fortran level 1)
+                    const T t1km1 = (K > 0) ? T1c[(K > 0 ? K - 1 : 0) * TW + 1 + lane] : T(0);
+                    tw[m] = s_fnm[K] * t1c + s_fnp[K] * t1km1;
+                    vfm[m] = vfm_n; vft[m] = vft_n;              // the faces of row j+1
                 }
             }
             stamp(0);
@@ -429,12 +425,10 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 if (has_above) w1_above = amt_ld(ww1_b, o3 + (unsigned)KPT * lev);
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    {
-                        const unsigned om = o3 + (unsigned)lv(m) * lev;
-                        told[m] = amt_ld_stream<1>(t_b, om);
-                        ftk[m] = amt_ld_stream<1>(ft_b, om);
-                        w1[m] = amt_ld_stream<1>(ww1_b, om);
-                    }
+                    const unsigned om = o3 + (unsigned)lv(m) * lev;
+                    told[m] = amt_ld_stream<1>(t_b, om);
+                    ftk[m] = amt_ld_stream<1>(ft_b, om);
+                    w1[m] = amt_ld_stream<1>(ww1_b, om);
                 }
             }
             stamp(2);
@@ -445,12 +439,10 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 const T dmdt = DM[lane];
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    {
-                        const int K = kf + m;
-                        const T inc = s_dnw[K] * (dmdt + dv[m] + mu_tend) / msfty;   // :161
-                        AP[K * 64 + lane] = inc;
-                        if (m == KPT - 1) inc_last = inc;
-                    }
+                    const int K = kf + m;
+                    const T inc = s_dnw[K] * (dmdt + dv[m] + mu_tend) / msfty;   // :161
+                    AP[K * 64 + lane] = inc;
+                    if (m == KPT - 1) inc_last = inc;
                 }
             }
             stamp(4);
@@ -467,26 +459,24 @@ __global__ __launch_bounds__(KPT >= 15 ? 320 : KPT >= 8 ? 704 : 1024) void amt_m
                 T wd_k = (kf == 0) ? T(0) : (wwu - w1[0]) * tw[0];   // wdtn(i,1) = 0 (:220)
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
-                    {
-                        const unsigned om = o3 + (unsigned)lv(m) * lev;
-                        const int K = kf + m;
-                        const bool real = FULL || m < nlev;          // wave-uniform
-                        const T wout = wwu - w1[m];                  // :170
-                        if (real) amt_st_stream(ww_b, om, wout);
-                        // wdtn at level K+1 (:221,:227)
-                        T wd_n = T(0);
-                        const T wwu_n = (m + 1 < KPT) ? AP[(m + 1 < KPT ? K + 1 : K) * 64 + lane] : wwu - inc_last;
-                        if (m + 1 < KPT) {
-                            wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
-                            if (!FULL && K + 1 >= nk) wd_n = T(0);                            // wdtn(kde) = 0, :221
-                        } else if (has_above) {
-                            wd_n = (wwu_n - w1_above) * tw_above;
-                        }
-                        if (real) amt_st_stream(tave_b, om, told[m]);                                // :211
-                        const T tb = told[m] + msfty * dts * ftk[m];                          // :212
-                        if (real) amt_st_stream(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));   // :237-246
-                        wwu = wwu_n; wd_k = wd_n;
+                    const unsigned om = o3 + (unsigned)lv(m) * lev;
+                    const int K = kf + m;
+                    const bool real = FULL || m < nlev;          // wave-uniform
+                    const T wout = wwu - w1[m];                  // :170
+                    if (real) amt_st_stream(ww_b, om, wout);
+                    // wdtn at level K+1 (:221,:227)
+                    T wd_n = T(0);
+                    const T wwu_n = (m + 1 < KPT) ? AP[(m + 1 < KPT ? K + 1 : K) * 64 + lane] : wwu - inc_last;
+                    if (m + 1 < KPT) {
+                        wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
+                        if (!FULL && K + 1 >= nk) wd_n = T(0);                            // wdtn(kde) = 0, :221
+                    } else if (has_above) {
+                        wd_n = (wwu_n - w1_above) * tw_above;
                     }
+                    if (real) amt_st_stream(tave_b, om, told[m]);                                // :211
+                    const T tb = told[m] + msfty * dts * ftk[m];                          // :212
+                    if (real) amt_st_stream(t_b, om, tb - dts * msfty * ( hf[m] + s_rdnw[K] * (wd_n - wd_k) ));   // :237-246
+                    wwu = wwu_n; wd_k = wd_n;
                 }
             }
             // No barrier here.  What the next row's P1 writes (its own AP slots, and the T1 buffer
