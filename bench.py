@@ -323,15 +323,18 @@ def main():
             torch.cuda.synchronize()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]   # one per sweep (median)
     fence()
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(a.steps):
+    for k in range(a.steps):
         stepper.step()
+        marks[k].record()
     ev1.record()
     fence()
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
+    per_sweep = [(ev0 if k == 0 else marks[k - 1]).elapsed_time(marks[k]) for k in range(a.steps)]
 
     if world > 1:
         rdev = device if a.backend == "nccl" else torch.device("cpu")
@@ -368,6 +371,7 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_median": round(float(np.median(per_sweep)), 4) if per_sweep else None,   # rank 0's sweeps
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
