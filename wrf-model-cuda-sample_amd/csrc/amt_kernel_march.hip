@@ -1092,7 +1092,8 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
     // workgroups per CU, so the sweep takes about  rounds(r) * (r + 0.5)  row-times.  Pick the r
     // that minimises it: for the whole 4096-row domain any r near 32 is within 1 %, but for a
     // 510-row j-slab (8 GPUs) r = 32 would leave the last round 6 % full (1040 workgroups on 256
-    // CUs) and cost 17 % more than r = 11.  Small launches get short blocks (more workgroups).
+    // CUs) and cost 17 % more than r = 11.  Small launches get short blocks, down to one row (more
+    // workgroups: 64x40x64 takes 12 us with r = 1, 27 us with r = 4).
     int jrows = amt_env_int("AMT_MARCH_JROWS", 0);
     if (jrows < 1) {
         static int slots = 0;
@@ -1108,13 +1109,12 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
         const int per_cu = (int)((160u * 1024u) / (lds_need ? lds_need : 1));     // LDS is what bounds residency
         const long sl = (long)slots * (per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu);
         double best = 1e300;
-        for (int r = 4; r <= 64 && r <= nj; ++r) {
+        for (int r = 1; r <= 64 && r <= nj; ++r) {
             const long blocks = (long)g.ntile_i * ((nj + r - 1) / r);
             const long rounds = (blocks + sl - 1) / sl;
             const double cost = (double)rounds * (r + 0.5);
             if (cost < best - 1e-9 || (cost < best + 1e-9 && r > jrows)) { best = cost; jrows = r; }
         }
-        if (jrows < 1) jrows = nj;                                // nj < 4
     }
     if (jrows > nj) jrows = nj;
     const long max_rows = amt_march_max_rows(p);
