@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- advance_mu_t sweeps on N MI355X, one JSON line on rank 0.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts N rank processes itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one advance_mu_t sweep (one acoustic sub-step's call) over the whole
 4096 x 60 x 4096 fp64 domain (BASELINE.json configs[2]/[3]); inputs are resident in HBM before
 the timed region.  With N > 1 the SAME domain is split into N j-slabs (strong scaling), each
-rank trades its one-row input halos over RCCL send/recv every sweep
-(wrf-model-cuda-sample_amd/patch.py) while its interior rows compute.
+rank trades its one-row input halos over RCCL send/recv every sweep while its interior rows
+compute.  Default N > 1 stepper: the native C++ runtime behind the C-ABI (amt_slab_*, the path a
+Fortran host calls; patch.NativeSlabStepper hands it pointers); --stepper torch runs the same
+schedule through torch.distributed P2P ops (patch.SlabStepper) as a cross-check.  Both start from
+NaN-poisoned halo rows and are verified against the oracle after the first sweep.
 
 Output keys beyond the driver's contract:
   roofline      algorithmic HBM bytes of one sweep (W*NI*NJ*(11*NK+14))
@@ -65,7 +68,12 @@ def parse():
     ap.add_argument("--emulate-rank", type=int, default=-1)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: bring-up mode -- halo rows staged through the host, ranks may share a GPU "
-                         "(RCCL refuses that); never a performance number")
+                         "(RCCL refuses that); torch stepper only; never a performance number")
+    ap.add_argument("--stepper", choices=("native", "torch"), default="native",
+                    help="N > 1: native = amt_slab_* (ncclSend/ncclRecv inside the C++ runtime, what a Fortran "
+                         "host calls); torch = torch.distributed P2P ops around the same launches")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0,
+                    help="self-launch (N > 1 without a launcher): give up and end every rank after this many seconds")
     return ap.parse_args()
 
 
@@ -210,10 +218,51 @@ def emulate_one_rank(a):
                       "note": "halo rows by device-to-device copy; no xGMI transfer, no neighbour skew"}), flush=True)
 
 
-def main():
-    a = parse()
-    if a.emulate_world > 1:
-        return emulate_one_rank(a)
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it: this process (which never touches a
+    GPU) starts N rank processes of this same script with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, lets rank 0 print the JSON line on the inherited stdout, and
+    returns the worst exit code.  A rank that dies takes the others down with it (by pid)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    nonce = f"{os.getpid()}-{time.time_ns()}"
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   AMT_RENDEZVOUS_NONCE=nonce, AMT_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.monotonic() + a.launch_timeout
+    rc = 0
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at = time.monotonic()
+            rc = bad[0]
+        timed_out = time.monotonic() > deadline
+        if timed_out or (failed_at is not None and time.monotonic() - failed_at > 10.0):
+            for p in procs:                      # the exact processes started above, nothing else
+                if p.poll() is None:
+                    p.kill()
+            if timed_out:
+                print(f"bench.py: self-launch timed out after {a.launch_timeout:.0f} s", file=sys.stderr)
+                rc = rc or 124
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+        if p.returncode and not rc:
+            rc = p.returncode
+    return rc
+
+
+def run_rank(a):
     import torch
     import torch.distributed as dist
     import __graft_entry__ as g
@@ -221,21 +270,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        a.gpus = world
+    a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    ndev = torch.cuda.device_count()
     if a.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
+        a.stepper = "torch"                        # bring-up mode: host-staged rows, ranks may share a GPU
+        local_rank = local_rank % ndev
+    elif world > 1 and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible (RCCL needs one "
+                         "GPU per rank; --backend gloo shares a GPU for bring-up)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    native = world > 1 and a.stepper == "native"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
+        if a.backend == "nccl" and not native:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
+            # native stepper: RCCL lives inside the C++ runtime; torch.distributed (gloo, host side)
+            # only carries the communicator id, the barriers and the max over ranks of the timings
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = g.load_package()
@@ -248,6 +302,9 @@ def main():
     sb = S.slab_bounds(gb, rank, world)
     cfg = pkg.GridConfig()
 
+    # every launch, copy and event of this rank goes to ONE stream (torch's current one)
+    main_stream = torch.cuda.Stream(device=device) if native else torch.cuda.current_stream(device)
+    torch.cuda.set_stream(main_stream)
     dev = S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device=device)
     probe_ms = None
     if a.probe_placements > 1:
@@ -277,27 +334,50 @@ def main():
                                                   t.element_size(), _ct.c_void_p(t.data_ptr()), _ct.c_uint64(a.seed), *fa))
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-    if world > 1:
-        # poison the halo rows so that only a working exchange gives the right answer
-        for name in S.HALO_FROM_ABOVE:
+
+    def poison_halos():
+        # only a working exchange gives the right answer
+        if world > 1:
             if rank < world - 1:
-                dev.arrays[name][-1].fill_(float("nan"))
-        if rank > 0:
-            dev.arrays["t_1"][0].fill_(float("nan"))
-    stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap,
-                                    variant=a.variant, stage_through_host=(a.backend == "gloo"))
+                for name in S.HALO_FROM_ABOVE:
+                    dev.arrays[name][-1].fill_(float("nan"))
+            if rank > 0:
+                dev.arrays["t_1"][0].fill_(float("nan"))
+
+    poison_halos()
+    torch.cuda.synchronize()
+    ranks_seen = 1
+    if native:
+        # phase 1, no collective: every rank must be able to open RCCL; agree before anyone blocks
+        # in ncclCommInitRank waiting for a rank that cannot come
+        err = ""
+        try:
+            uid = [pkg.patch.NativeSlabStepper.comm_unique_id() if rank == 0 else None]
+            if rank != 0:
+                pkg.patch.NativeSlabStepper.comm_unique_id()
+        except pkg.AmtError as e:
+            err, uid = str(e), [None]
+        flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 0.5:
+            raise SystemExit(f"rank {rank}: RCCL is not usable for the native stepper: {err or 'another rank failed'}")
+        dist.broadcast_object_list(uid, src=0)
+        stepper = pkg.patch.NativeSlabStepper(dev, rank, world, uid[0], stream=main_stream,
+                                              overlap=not a.no_overlap, variant=a.variant)
+        ranks_seen = stepper.comm_info()[1]
+    else:
+        stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap,
+                                        variant=a.variant, stage_through_host=(a.backend == "gloo"))
+        if world > 1:
+            ranks_seen = dist.get_world_size()
     torch.cuda.synchronize()
     if world > 1:
         # establish the RCCL point-to-point connections outside any timed or verified step (the
-        # first send/recv between two ranks builds their communicator, which takes seconds);
+        # first send/recv between two ranks builds their channels, which takes seconds);
         # the inputs are static, so an extra exchange changes nothing
         stepper.exchange_halos()
         torch.cuda.synchronize()
-        if rank < world - 1:                       # re-poison: the verification must see the in-step exchange
-            for name in S.HALO_FROM_ABOVE:
-                dev.arrays[name][-1].fill_(float("nan"))
-        if rank > 0:
-            dev.arrays["t_1"][0].fill_(float("nan"))
+        poison_halos()                             # the verification must see the in-step exchange
         torch.cuda.synchronize()
         dist.barrier()
 
@@ -326,23 +406,25 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]   # one per sweep (median)
     fence()
     t0 = time.perf_counter()
-    ev0.record()
+    ev0.record(main_stream)
     for k in range(a.steps):
         stepper.step()
-        marks[k].record()
-    ev1.record()
+        marks[k].record(main_stream)
+    ev1.record(main_stream)
     fence()
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     per_sweep = [(ev0 if k == 0 else marks[k - 1]).elapsed_time(marks[k]) for k in range(a.steps)]
 
+    rank_ms = [ev_ms / max(a.steps, 1)] * 2                       # min, max over ranks of the event ms per sweep
     if world > 1:
-        rdev = device if a.backend == "nccl" else torch.device("cpu")
+        rdev = device if dist.get_backend() == "nccl" else torch.device("cpu")
         t = torch.tensor([wall, ev_ms, 1.0 if verified in (None, True) else 0.0], device=rdev, dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tmin = t.clone()
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        rank_ms = [float(tmin[1]) / max(a.steps, 1), float(tmax[1]) / max(a.steps, 1)]
         wall, ev_ms = float(tmax[0]), float(tmax[1])
         if verified is not None:
             verified = bool(tmin[2] > 0.5)
@@ -354,13 +436,16 @@ def main():
         ev_per_step_s = ev_ms * 1e-3 / max(a.steps, 1)
         abytes = algorithmic_bytes(a.ni, a.nk, a.nj, itemsize)
         achieved = abytes / world / ev_per_step_s / 1e9              # GB/s per GPU (slowest rank)
-        traffic = None
+        traffic, traffic_source = None, None
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():
             try:
                 rec = json.loads(tf.read_text()).get(f"{a.ni}x{a.nk}x{a.nj}_{a.dtype}_n{world}")
                 if rec:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = (f"profiles/hbm_traffic.json <- {rec.get('source', '?')} (rocprofv3 --pmc passes of "
+                                      f"this command, collected by profiles/collect.sh; a recorded measurement, "
+                                      f"not re-measured in this run)")
             except Exception:
                 traffic = None
         out = {
@@ -384,8 +469,15 @@ def main():
                        "halo_transport": ("rccl" if a.backend == "nccl" else "gloo-host-staged (bring-up)") if world > 1 else None,
                        "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep(),
                        "placement_probe_ms": probe_ms},
+            "stepper": ("native amt_slab_* (C++ runtime, ncclSend/ncclRecv)" if native else
+                        "torch.distributed P2P (patch.SlabStepper)") if world > 1 else "single launch per sweep",
+            "ranks_seen": ranks_seen,
+            "rank_ms_per_step_min_max": [round(x, 4) for x in rank_ms],
+            "launched_by": "bench.py self-launch" if os.environ.get("AMT_BENCH_SELF_LAUNCHED") else
+                           ("external launcher" if world > 1 else "direct"),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": abytes // world,
                          "kernel_ms_per_launch": round(ev_per_step_s * 1e3, 4),
                          "aggregate_GBps": round(abytes / ev_per_step_s / 1e9, 1)},
@@ -404,9 +496,20 @@ def main():
 
     if world > 1:
         dist.barrier()
+        if native:
+            stepper.close()
         dist.destroy_process_group()
     if verified is False:
         raise SystemExit(3)
+
+
+def main():
+    a = parse()
+    if a.emulate_world > 1:
+        return emulate_one_rank(a)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))
+    return run_rank(a)
 
 
 if __name__ == "__main__":

@@ -193,12 +193,27 @@ int amt_domain_create(amt_domain **out, int dtype_bytes,
                       int ids, int ide, int jds, int jde, int kde,
                       int ims, int ime, int jms, int jme, int kms, int kme,
                       int its, int ite, int jts, int jte, int kts, int kte);
+/* The same handle over device arrays the CALLER owns (a host model that already keeps its state
+ * on the GPU, as WRF's arrays would be): fields[f] is the device pointer of field f (enum
+ * amt_field, all AMT_F_COUNT of them, laid out as above); hip_stream is the hipStream_t the
+ * handle's work is enqueued on, NULL = a stream of its own.  Nothing is copied; destroy frees
+ * neither the arrays nor the caller's stream. */
+int amt_domain_wrap(amt_domain **out, int dtype_bytes,
+                    int periodic_x, int specified, int nested,
+                    int ids, int ide, int jds, int jde, int kde,
+                    int ims, int ime, int jms, int jme, int kms, int kme,
+                    int its, int ite, int jts, int jte, int kts, int kte,
+                    void *const *fields, void *hip_stream);
 int amt_domain_destroy(amt_domain *d);
 int amt_domain_set_scalars(amt_domain *d, double rdx, double rdy, double dts, double epssm);
 int amt_domain_set_variant(amt_domain *d, int variant);
 /* whole-array copies in the (ims:ime[,kms:kme][,jms:jme]) layout; synchronous */
 int amt_domain_upload(amt_domain *d, int field, const void *host);
 int amt_domain_download(amt_domain *d, int field, void *host);
+/* rows j_lo..j_hi (Fortran indices inside jms:jme) of a rank-3 or rank-2 field; `host` holds
+ * exactly those rows (contiguous in this layout); synchronous */
+int amt_domain_upload_rows(amt_domain *d, int field, int j_lo, int j_hi, const void *host);
+int amt_domain_download_rows(amt_domain *d, int field, int j_lo, int j_hi, void *host);
 /* fill every field from amt_synth.h; (gi0,gk0,gj0) = GLOBAL zero-based index of this
  * patch's element (ims,kms,jms); (gidim,gkdim,gjdim) = GLOBAL memory extents */
 int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,
@@ -250,9 +265,16 @@ typedef struct amt_slab amt_slab;
 int amt_set_device(int device);              /* hipSetDevice for hosts without a HIP binding     */
 /* rank 0: a fresh communicator id (ncclGetUniqueId) to hand to every rank */
 int amt_comm_unique_id(void *id_out /* AMT_UNIQUE_ID_BYTES */);
-/* the same through a file for hosts without MPI: rank 0 creates and publishes the id as
- * `path`, the others wait up to timeout_s for it; every rank gets the id in id_out */
-int amt_comm_rendezvous_file(const char *path, int rank, double timeout_s, void *id_out);
+/* The same through a file for hosts without MPI.  Rank 0 creates the id and publishes it as
+ * `path` behind a header carrying `nonce`; every other rank waits (up to timeout_s) for a file
+ * with ITS nonce, reads the id and acknowledges; rank 0 returns when all world-1 ranks have it and
+ * removes the files.  `nonce` ties the file to one launch: a file left by another (crashed)
+ * launch is never accepted, however fresh.  nonce = 0 means amt_comm_launch_nonce(). */
+int amt_comm_rendezvous_file(const char *path, uint64_t nonce, int rank, int world,
+                             double timeout_s, void *id_out);
+/* a value all processes of one launch agree on and two launches do not: AMT_RENDEZVOUS_NONCE if
+ * set, else the launcher (TORCHELASTIC_RUN_ID, parent pid + its start time) and MASTER_PORT */
+uint64_t amt_comm_launch_nonce(void);
 /* collective over the `world` ranks (ncclCommInitRank); the domain must outlive the slab */
 int amt_slab_create(amt_slab **out, amt_domain *domain, int rank, int world,
                     const void *unique_id, int flags);
@@ -262,6 +284,12 @@ int amt_slab_step(amt_slab *slab, int n_sweeps);             /* asynchronous    
 int amt_slab_step_timed(amt_slab *slab, int n_sweeps, float *ms_total);
 int amt_slab_sync(amt_slab *slab);
 long amt_slab_halo_bytes(const amt_slab *slab);              /* sent (= received) per sweep      */
+/* rank and size as the communicator reports them (0 of 1 without one) */
+int amt_slab_comm_info(const amt_slab *slab, int *rank, int *world);
+/* reporting aids for hosts without MPI: drain this rank's streams, then wait for every rank
+ * (barrier) / replace *x by its maximum over the ranks.  The sweep itself has no collective. */
+int amt_slab_barrier(amt_slab *slab);
+int amt_slab_max(amt_slab *slab, double *x);
 
 /* ------------------------------------------------------------------------
  * (6) Profiling aid: a plain streaming copy of nbytes (device to device) that moves

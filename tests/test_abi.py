@@ -104,22 +104,3 @@ def test_product_never_touches_the_oracle():
     for f in files:
         m = pat.search(f.read_text())
         assert not m, f"{f}: {m.group(0)}"
-
-
-def test_rendezvous_reader_ignores_a_stale_file(tmp_path):
-    """amt_comm_rendezvous_file, reader side (no GPU, no RCCL needed): a file left by an earlier
-    launch is not taken for this one's id; a fresh one is read back byte for byte."""
-    import ctypes
-    import os
-    import time
-    import __graft_entry__ as g
-    pkg = g.load_package()
-    L = pkg.load_library()
-    path = tmp_path / "uid"
-    path.write_bytes(b"x" * 128)
-    os.utime(path, (time.time() - 600, time.time() - 600))
-    buf = (ctypes.c_char * 128)()
-    assert L.amt_comm_rendezvous_file(str(path).encode(), 1, 0.2, buf) == pkg.lib.ERR_COMM
-    path.write_bytes(bytes(range(128)))
-    assert L.amt_comm_rendezvous_file(str(path).encode(), 1, 1.0, buf) == 0
-    assert bytes(buf) == bytes(range(128))

@@ -43,3 +43,19 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "needs a GPU" in (r.stdout + r.stderr)
+
+
+def test_self_launch_without_gpus_fails_fast_and_loud():
+    """`python bench.py --gpus 2` with no launcher starts its own ranks; without a GPU every rank
+    refuses (no CPU fallback) and the parent returns their error instead of hanging."""
+    import os
+    import time
+    import torch
+    if torch.cuda.is_available():
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--launch-timeout", "120"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "needs a GPU" in (r.stdout + r.stderr)
+    assert time.time() - t0 < 120

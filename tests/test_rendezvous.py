@@ -1,0 +1,72 @@
+"""amt_comm_rendezvous_file: the launch nonce (a file left by an earlier launch on
+the same path must never be taken for this launch's).  Ranks other than 0 never touch RCCL, so this
+runs without a GPU: the "rank 0" side is written by hand in the documented format
+(8-byte magic, 8-byte nonce, the id)."""
+import ctypes
+import struct
+import threading
+import time
+
+import pytest
+
+MAGIC = b"AMTUID02"
+
+
+def _publish(path, nonce, ident):
+    path.write_bytes(MAGIC + struct.pack("<Q", nonce) + ident)
+
+
+def test_other_launchs_file_is_refused_however_fresh(pkg, tmp_path):
+    from wrf_model_cuda_sample_amd import lib
+    L = pkg.load_library()
+    out = (ctypes.c_char * 128)()
+    path = tmp_path / "uid"
+    _publish(path, 1234, bytes(range(128)))                     # written just now, by "another launch"
+    rc = L.amt_comm_rendezvous_file(str(path).encode(), 999, 1, 2, 0.3, out)
+    assert rc == lib.ERR_COMM
+    assert b"another launch" in L.amt_last_error()
+    assert not (tmp_path / "uid.ack.1").exists()
+
+
+def test_stale_file_is_skipped_until_this_launchs_arrives(pkg, tmp_path):
+    from wrf_model_cuda_sample_amd import lib
+    L = pkg.load_library()
+    out = (ctypes.c_char * 128)()
+    path = tmp_path / "uid"
+    ident = bytes((7 * i) % 251 for i in range(128))
+    _publish(path, 1, b"\x55" * 128)                            # stale
+
+    def rank0_later():
+        time.sleep(0.3)
+        tmp = tmp_path / "uid.tmp"
+        tmp.write_bytes(MAGIC + struct.pack("<Q", 42) + ident)
+        tmp.rename(path)
+    t = threading.Thread(target=rank0_later)
+    t.start()
+    lib.check(L.amt_comm_rendezvous_file(str(path).encode(), 42, 3, 4, 10.0, out))
+    t.join()
+    assert bytes(out) == ident
+    assert (tmp_path / "uid.ack.3").read_bytes() == struct.pack("<Q", 42)
+
+
+def test_launch_nonce_is_stable_in_a_process_and_follows_the_environment(pkg, monkeypatch):
+    L = pkg.load_library()
+    monkeypatch.delenv("AMT_RENDEZVOUS_NONCE", raising=False)
+    a, b = L.amt_comm_launch_nonce(), L.amt_comm_launch_nonce()
+    assert a == b and a != 0
+    monkeypatch.setenv("AMT_RENDEZVOUS_NONCE", "launch-1")
+    c = L.amt_comm_launch_nonce()
+    monkeypatch.setenv("AMT_RENDEZVOUS_NONCE", "launch-2")
+    d = L.amt_comm_launch_nonce()
+    assert len({a, c, d}) == 3
+
+
+def test_bad_arguments(pkg, tmp_path):
+    from wrf_model_cuda_sample_amd import lib
+    L = pkg.load_library()
+    out = (ctypes.c_char * 128)()
+    p = str(tmp_path / "x").encode()
+    assert L.amt_comm_rendezvous_file(p, 1, 2, 2, 0.1, out) == lib.ERR_INVALID_ARG      # rank outside the world
+    assert L.amt_comm_rendezvous_file(p, 1, -1, 2, 0.1, out) == lib.ERR_INVALID_ARG
+    assert L.amt_comm_rendezvous_file(b"", 1, 1, 2, 0.1, out) == lib.ERR_INVALID_ARG
+    assert L.amt_comm_rendezvous_file(p, 1, 1, 2, 0.1, None) == lib.ERR_INVALID_ARG

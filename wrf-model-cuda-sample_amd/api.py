@@ -36,6 +36,15 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
+def _expected_sizes(ims, ime, jms, jme, kms, kme):
+    """Element counts of the 26 array arguments, in argument order (18 before the scalars, 8 after),
+    for the memory extents ims:ime, kms:kme, jms:jme (module_small_step_em.f90:30-64)."""
+    idim, kdim, jdim = ime - ims + 1, kme - kms + 1, jme - jms + 1
+    rank3 = {0, 1, 2, 3, 4, 5, 13, 14, 15, 16}          # ww ww_1 u u_1 v v_1 | t t_1 t_ave ft
+    want = [(jdim * kdim * idim) if n in rank3 else (jdim * idim) for n in range(18)]
+    return want + [kdim] * 4 + [jdim * idim] * 4
+
+
 def bind_device_call(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
                      t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,
                      msfuy, msfvx_inv, msftx, msfty, config_flags,
@@ -51,9 +60,11 @@ def bind_device_call(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, m
     dt = ww.dtype
     if dt not in (torch.float32, torch.float64):
         raise TypeError(f"unsupported dtype {dt}")
-    for a in arrays:
-        if not (_is_torch(a) and a.is_cuda and a.dtype == dt and a.is_contiguous()):
-            raise TypeError("device call needs contiguous CUDA tensors of one dtype")
+    # the kernel gets raw pointers: a tensor of another extent (a slab patch bound with the whole
+    # domain's bounds, say) would be read or written out of bounds on the device
+    for a, n in zip(arrays, _expected_sizes(ims, ime, jms, jme, kms, kme)):
+        if not (_is_torch(a) and a.is_cuda and a.dtype == dt and a.is_contiguous() and a.numel() == n):
+            raise TypeError("device call needs contiguous CUDA tensors of one dtype and of the memory extents")
     real = ctypes.c_float if dt == torch.float32 else ctypes.c_double
     fn = L.amt_advance_mu_t_device_f32 if dt == torch.float32 else L.amt_advance_mu_t_device_f64
     if stream is None:
@@ -87,10 +98,7 @@ def advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf,
     arrays_a = (ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1, t_ave, ft, mu_tend)
     arrays_b = (dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty)
     ints = [int(x) for x in (ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte)]
-    idim, kdim, jdim = ime - ims + 1, kme - kms + 1, jme - jms + 1
-    rank3 = {0, 1, 2, 3, 4, 5, 13, 14, 15, 16}
-    want = [(jdim * kdim * idim) if n in rank3 else (jdim * idim) for n in range(18)]
-    want += [kdim] * 4 + [jdim * idim] * 4
+    want = _expected_sizes(ims, ime, jms, jme, kms, kme)
     flags = list(flags_as_ints(config_flags))
 
     if _is_torch(ww):

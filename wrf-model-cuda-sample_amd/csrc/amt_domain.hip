@@ -6,25 +6,33 @@ extern "C" int amt_domain_destroy(amt_domain *d)
 {
     if (!d) return AMT_OK;
     DeviceScope scope(d->device);
-    for (void *&q : d->field)
-        if (q) { (void)hipFree(q); q = nullptr; }
+    if (d->owns_fields)
+        for (void *&q : d->field)
+            if (q) { (void)hipFree(q); q = nullptr; }
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
-    if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->stream && d->owns_stream) (void)hipStreamDestroy(d->stream);
     delete d;
     return AMT_OK;
 }
 
-extern "C" int amt_domain_create(amt_domain **out, int dtype_bytes,
-                                 int periodic_x, int specified, int nested,
-                                 int ids, int ide, int jds, int jde, int kde,
-                                 int ims, int ime, int jms, int jme, int kms, int kme,
-                                 int its, int ite, int jts, int jte, int kts, int kte)
+// fields == nullptr: allocate the 26 arrays (amt_domain_create).  Otherwise adopt the caller's
+// device arrays and, when given, the caller's stream (amt_domain_wrap): nothing is copied and
+// nothing of the caller's is freed by amt_domain_destroy.
+static int amt_domain_make(amt_domain **out, int dtype_bytes,
+                           int periodic_x, int specified, int nested,
+                           int ids, int ide, int jds, int jde, int kde,
+                           int ims, int ime, int jms, int jme, int kms, int kme,
+                           int its, int ite, int jts, int jte, int kts, int kte,
+                           void *const *fields, void *hip_stream)
 {
     if (!out) return amt_fail(AMT_ERR_INVALID_ARG, "null out pointer");
     *out = nullptr;
     if (dtype_bytes != 4 && dtype_bytes != 8) return amt_fail(AMT_ERR_INVALID_ARG, "dtype_bytes must be 4 or 8");
     if (ime < ims || jme < jms || kme < kms) return amt_fail(AMT_ERR_PRECONDITION, "empty memory extents");
+    if (fields)
+        for (int f = 0; f < AMT_F_COUNT; ++f)
+            if (!fields[f]) return amt_fail(AMT_ERR_INVALID_ARG, "amt_domain_wrap: field %d is a null pointer", f);
     int ndev = 0;
     AMT_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return amt_fail(AMT_ERR_NO_DEVICE, "no HIP device visible");
@@ -35,12 +43,17 @@ extern "C" int amt_domain_create(amt_domain **out, int dtype_bytes,
     d->ids = ids; d->ide = ide; d->jds = jds; d->jde = jde; d->kde = kde;
     d->ims = ims; d->ime = ime; d->jms = jms; d->jme = jme; d->kms = kms; d->kme = kme;
     d->its = its; d->ite = ite; d->jts = jts; d->jte = jte; d->kts = kts; d->kte = kte;
+    d->owns_fields = (fields == nullptr);
+    d->owns_stream = (hip_stream == nullptr);
     hipError_t e = hipGetDevice(&d->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (hip_stream) d->stream = static_cast<hipStream_t>(hip_stream);
+    else if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&d->ev0);
     if (e == hipSuccess) e = hipEventCreate(&d->ev1);
-    for (int f = 0; f < AMT_F_COUNT && e == hipSuccess; ++f)
-        e = hipMalloc(&d->field[f], d->count(f) * (size_t)dtype_bytes);
+    for (int f = 0; f < AMT_F_COUNT && e == hipSuccess; ++f) {
+        if (fields) d->field[f] = fields[f];
+        else e = hipMalloc(&d->field[f], d->count(f) * (size_t)dtype_bytes);
+    }
     if (e != hipSuccess) {
         amt_domain_destroy(d);
         return amt_fail(e == hipErrorOutOfMemory ? AMT_ERR_ALLOC : AMT_ERR_HIP,
@@ -48,6 +61,28 @@ extern "C" int amt_domain_create(amt_domain **out, int dtype_bytes,
     }
     *out = d;
     return AMT_OK;
+}
+
+extern "C" int amt_domain_create(amt_domain **out, int dtype_bytes,
+                                 int periodic_x, int specified, int nested,
+                                 int ids, int ide, int jds, int jde, int kde,
+                                 int ims, int ime, int jms, int jme, int kms, int kme,
+                                 int its, int ite, int jts, int jte, int kts, int kte)
+{
+    return amt_domain_make(out, dtype_bytes, periodic_x, specified, nested, ids, ide, jds, jde, kde,
+                           ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte, nullptr, nullptr);
+}
+
+extern "C" int amt_domain_wrap(amt_domain **out, int dtype_bytes,
+                               int periodic_x, int specified, int nested,
+                               int ids, int ide, int jds, int jde, int kde,
+                               int ims, int ime, int jms, int jme, int kms, int kme,
+                               int its, int ite, int jts, int jte, int kts, int kte,
+                               void *const *fields, void *hip_stream)
+{
+    if (!fields) return amt_fail(AMT_ERR_INVALID_ARG, "amt_domain_wrap needs the %d device pointers", (int)AMT_F_COUNT);
+    return amt_domain_make(out, dtype_bytes, periodic_x, specified, nested, ids, ide, jds, jde, kde,
+                           ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte, fields, hip_stream);
 }
 
 extern "C" int amt_domain_set_scalars(amt_domain *d, double rdx, double rdy, double dts, double epssm)
@@ -82,6 +117,36 @@ extern "C" int amt_domain_download(amt_domain *d, int field, void *host)
     AMT_HIP(hipMemcpyAsync(host, d->field[field], d->count(field) * d->dtype_bytes, hipMemcpyDeviceToHost, d->stream));
     AMT_HIP(hipStreamSynchronize(d->stream));
     return AMT_OK;
+}
+
+// rows j_lo..j_hi (Fortran indices, inside jms:jme) of a rank-3 or rank-2 field: contiguous in the
+// (i,k,j) layout, so one copy each; `host` holds just those rows.  Synchronous.
+static int amt_domain_copy_rows(amt_domain *d, int field, int j_lo, int j_hi, void *host, bool up)
+{
+    if (!d || !host || field < 0 || field >= AMT_F_COUNT) return amt_fail(AMT_ERR_INVALID_ARG, "bad row-copy argument");
+    const int rank = amt_field_rank(field);
+    if (rank == 1) return amt_fail(AMT_ERR_INVALID_ARG, "field %d has no j rows", field);
+    if (j_lo < d->jms || j_hi > d->jme || j_hi < j_lo)
+        return amt_fail(AMT_ERR_PRECONDITION, "rows %d:%d not inside memory jms:jme=%d:%d", j_lo, j_hi, d->jms, d->jme);
+    const size_t idim = d->ime - d->ims + 1, kdim = d->kme - d->kms + 1;
+    const size_t row = (rank == 3 ? idim * kdim : idim) * (size_t)d->dtype_bytes;
+    char *dev = static_cast<char *>(d->field[field]) + (size_t)(j_lo - d->jms) * row;
+    const size_t bytes = (size_t)(j_hi - j_lo + 1) * row;
+    DeviceScope scope(d->device);
+    if (up) AMT_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, d->stream));
+    else AMT_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, d->stream));
+    AMT_HIP(hipStreamSynchronize(d->stream));
+    return AMT_OK;
+}
+
+extern "C" int amt_domain_upload_rows(amt_domain *d, int field, int j_lo, int j_hi, const void *host)
+{
+    return amt_domain_copy_rows(d, field, j_lo, j_hi, const_cast<void *>(host), true);
+}
+
+extern "C" int amt_domain_download_rows(amt_domain *d, int field, int j_lo, int j_hi, void *host)
+{
+    return amt_domain_copy_rows(d, field, j_lo, j_hi, host, false);
 }
 
 extern "C" int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,

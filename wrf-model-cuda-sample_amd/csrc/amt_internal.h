@@ -104,6 +104,8 @@ struct amt_domain {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *field[AMT_F_COUNT] = {};
+    bool owns_fields = true;      // false: the arrays belong to the caller (amt_domain_wrap)
+    bool owns_stream = true;      // false: the stream belongs to the caller
     size_t count(int f) const
     {
         const size_t idim = ime - ims + 1, kdim = kme - kms + 1, jdim = jme - jms + 1;

@@ -26,6 +26,9 @@ struct AmtRccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 AmtRccl g_rccl;
@@ -51,6 +54,9 @@ int amt_rccl_load()
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
     r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) { dlclose(lib); return amt_fail(AMT_ERR_COMM, "librccl lacks a send/recv entry point"); }
     g_rccl = r;
@@ -86,40 +92,135 @@ extern "C" int amt_comm_unique_id(void *id_out)
 }
 
 // Rendezvous for hosts without MPI: rank 0 creates the id and publishes it as `path` (written
-// under a temporary name, then renamed), the other ranks wait for the file.  A file left by an
-// earlier launch must not be taken for this one's: rank 0 removes it first, and the others ignore
-// files last written more than a minute before they started waiting (use a fresh path per launch,
-// e.g. derived from the launcher's port, when relaunching faster than that).
-extern "C" int amt_comm_rendezvous_file(const char *path, int rank, double timeout_s, void *id_out)
+// under a temporary name, then renamed) behind a header that carries the LAUNCH NONCE; the other
+// ranks wait for a file whose nonce is theirs, read the id and acknowledge with `path.ack.<rank>`;
+// rank 0 waits for the world-1 acknowledgements and removes every file.  A file left behind by an
+// earlier launch (a crashed one: a completed one leaves nothing) carries another nonce and is
+// never taken for this launch's, however recently it was written.
+namespace {
+struct AmtRendezvousHeader {
+    char magic[8];
+    uint64_t nonce;
+};
+const char kRvMagic[8] = {'A', 'M', 'T', 'U', 'I', 'D', '0', '2'};
+
+uint64_t amt_fnv1a(uint64_t h, const void *data, size_t n)
 {
-    if (!path || !*path || !id_out || rank < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad rendezvous argument");
+    const unsigned char *q = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= q[i]; h *= 1099511628211ull; }
+    return h;
+}
+}  // namespace
+
+// A value every process of ONE launch computes identically and two launches do not share:
+// AMT_RENDEZVOUS_NONCE if set; else the launcher's run id (TORCHELASTIC_RUN_ID + restart count);
+// else the parent process (pid and start time from /proc: the ranks of a launch are children
+// of one launcher) together with MASTER_PORT.  Never 0.
+extern "C" uint64_t amt_comm_launch_nonce(void)
+{
+    uint64_t h = 1469598103934665603ull;
+    if (const char *s = getenv("AMT_RENDEZVOUS_NONCE"); s && *s) {
+        h = amt_fnv1a(h, s, strlen(s));
+    } else {
+        // the launcher's run id alone may be a fixed word ("none" for a static rendezvous): always
+        // mix in the parent process as well
+        if (const char *t = getenv("TORCHELASTIC_RUN_ID"); t && *t) h = amt_fnv1a(h, t, strlen(t));
+        if (const char *t = getenv("TORCHELASTIC_RESTART_COUNT"); t && *t) h = amt_fnv1a(h, t, strlen(t));
+        const long ppid = (long)getppid();
+        h = amt_fnv1a(h, &ppid, sizeof ppid);
+        char statpath[64];
+        snprintf(statpath, sizeof statpath, "/proc/%ld/stat", ppid);
+        if (FILE *f = fopen(statpath, "r")) {
+            char buf[1024];
+            const size_t n = fread(buf, 1, sizeof buf - 1, f);
+            fclose(f);
+            buf[n] = 0;
+            // field 22 (starttime) counted after the last ')' of the command name
+            if (const char *q = strrchr(buf, ')')) {
+                int field = 2;
+                for (++q; *q && field < 22; ++q)
+                    if (*q == ' ') ++field;
+                const char *e = q;
+                while (*e && *e != ' ') ++e;
+                h = amt_fnv1a(h, q, (size_t)(e - q));
+            }
+        }
+        if (const char *t = getenv("MASTER_PORT"); t && *t) h = amt_fnv1a(h, t, strlen(t));
+    }
+    return h ? h : 1;
+}
+
+extern "C" int amt_comm_rendezvous_file(const char *path, uint64_t nonce, int rank, int world,
+                                        double timeout_s, void *id_out)
+{
+    if (!path || !*path || !id_out || rank < 0 || world < 1 || rank >= world)
+        return amt_fail(AMT_ERR_INVALID_ARG, "bad rendezvous argument");
+    if (nonce == 0) nonce = amt_comm_launch_nonce();
+    const auto t0 = std::chrono::steady_clock::now();
+    auto waited = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    auto ack_name = [&](int r) { return std::string(path) + ".ack." + std::to_string(r); };
     if (rank == 0) {
         (void)unlink(path);
+        for (int r = 1; r < world; ++r) (void)unlink(ack_name(r).c_str());
         int rc = amt_comm_unique_id(id_out);
         if (rc) return rc;
+        AmtRendezvousHeader hd;
+        memcpy(hd.magic, kRvMagic, 8);
+        hd.nonce = nonce;
         const std::string tmp = std::string(path) + ".tmp";
         FILE *f = fopen(tmp.c_str(), "wb");
         if (!f) return amt_fail(AMT_ERR_COMM, "cannot write %s", tmp.c_str());
-        const size_t n = fwrite(id_out, 1, AMT_UNIQUE_ID_BYTES, f);
+        const size_t n = fwrite(&hd, 1, sizeof hd, f) + fwrite(id_out, 1, AMT_UNIQUE_ID_BYTES, f);
         fclose(f);
-        if (n != AMT_UNIQUE_ID_BYTES || rename(tmp.c_str(), path) != 0)
+        if (n != sizeof hd + AMT_UNIQUE_ID_BYTES || rename(tmp.c_str(), path) != 0)
             return amt_fail(AMT_ERR_COMM, "cannot publish %s", path);
+        // wait until every other rank of THIS launch has the id, then leave nothing behind
+        for (int r = 1; r < world; ++r) {
+            const std::string an = ack_name(r);
+            for (;;) {
+                uint64_t got = 0;
+                if (FILE *g = fopen(an.c_str(), "rb")) {
+                    const size_t m = fread(&got, 1, sizeof got, g);
+                    fclose(g);
+                    if (m == sizeof got && got == nonce) break;
+                }
+                if (waited() > timeout_s) {
+                    (void)unlink(path);
+                    return amt_fail(AMT_ERR_COMM, "rank %d did not pick up %s within %.0f s", r, path, timeout_s);
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            }
+            (void)unlink(an.c_str());
+        }
+        (void)unlink(path);
         return AMT_OK;
     }
-    const time_t entered = time(nullptr);
-    const auto t0 = std::chrono::steady_clock::now();
+    bool saw_stale = false;
     for (;;) {
-        struct stat st;
-        if (stat(path, &st) == 0 && st.st_mtime >= entered - 60) {
-            if (FILE *f = fopen(path, "rb")) {
-                const size_t n = fread(id_out, 1, AMT_UNIQUE_ID_BYTES, f);
-                fclose(f);
-                if (n == AMT_UNIQUE_ID_BYTES) return AMT_OK;
+        if (FILE *f = fopen(path, "rb")) {
+            AmtRendezvousHeader hd;
+            char id[AMT_UNIQUE_ID_BYTES];
+            const size_t n = fread(&hd, 1, sizeof hd, f) + fread(id, 1, sizeof id, f);
+            fclose(f);
+            if (n == sizeof hd + sizeof id && memcmp(hd.magic, kRvMagic, 8) == 0) {
+                if (hd.nonce == nonce) {
+                    memcpy(id_out, id, sizeof id);
+                    const std::string an = ack_name(rank), tmp = an + ".tmp";
+                    FILE *g = fopen(tmp.c_str(), "wb");
+                    if (!g) return amt_fail(AMT_ERR_COMM, "cannot write %s", tmp.c_str());
+                    const size_t m = fwrite(&nonce, 1, sizeof nonce, g);
+                    fclose(g);
+                    if (m != sizeof nonce || rename(tmp.c_str(), an.c_str()) != 0)
+                        return amt_fail(AMT_ERR_COMM, "cannot acknowledge %s", path);
+                    return AMT_OK;
+                }
+                saw_stale = true;          // another launch's file: rank 0 of this one will replace it
             }
         }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-            return amt_fail(AMT_ERR_COMM, "no rendezvous file %s after %.0f s", path, timeout_s);
-        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        if (waited() > timeout_s)
+            return amt_fail(AMT_ERR_COMM, saw_stale ? "%s belongs to another launch (nonce mismatch) after %.0f s"
+                                                    : "no rendezvous file %s after %.0f s", path, timeout_s);
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
 }
 
@@ -131,6 +232,7 @@ struct amt_slab {
     ncclComm_t comm = nullptr;
     hipStream_t comm_stream = nullptr;
     hipEvent_t inputs_final = nullptr, edges_done = nullptr, t0 = nullptr, t1 = nullptr;
+    double *red = nullptr;               // one device double for amt_slab_barrier / amt_slab_max
 };
 
 extern "C" int amt_slab_destroy(amt_slab *s)
@@ -142,6 +244,7 @@ extern "C" int amt_slab_destroy(amt_slab *s)
     for (hipEvent_t e : {s->inputs_final, s->edges_done, s->t0, s->t1})
         if (e) (void)hipEventDestroy(e);
     if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
+    if (s->red) (void)hipFree(s->red);
     delete s;
     return AMT_OK;
 }
@@ -169,6 +272,7 @@ extern "C" int amt_slab_create(amt_slab **out, amt_domain *dom, int rank, int wo
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&s->t0, &s->t1})
         if (e == hipSuccess) e = hipEventCreate(ev);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->red, sizeof(double));
     if (e != hipSuccess) {
         amt_slab_destroy(s);
         return amt_fail(AMT_ERR_HIP, "amt_slab_create: %s", hipGetErrorString(e));
@@ -206,17 +310,26 @@ int amt_slab_enqueue_exchange(amt_slab *s, hipStream_t stream)
         return static_cast<char *>(d->field[f]) + (size_t)(j - d->jms) * count * d->dtype_bytes;
     };
     size_t n = 0;
-    // per pair of ranks the order of sends matches the order of receives on the other side
+    // per pair of ranks the order of sends matches the order of receives on the other side.
+    // A failing call must not leave the group open (every later RCCL call of this thread would
+    // be queued into it, the communicator's destruction included): remember the first error and
+    // always close the group.
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    auto note = [&](ncclResult_t r, const char *w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; what = w; } };
     AMT_NCCL(g_rccl.GroupStart());
     if (s->below >= 0)
-        for (int f : kHaloFromAbove) { void *q = row(f, d->jts, n); AMT_NCCL(g_rccl.Send(q, n, dt, s->below, s->comm, stream)); }
+        for (int f : kHaloFromAbove) { void *q = row(f, d->jts, n); note(g_rccl.Send(q, n, dt, s->below, s->comm, stream), "ncclSend"); }
     if (s->above >= 0)
-        for (int f : kHaloFromBelow) { void *q = row(f, d->jte, n); AMT_NCCL(g_rccl.Send(q, n, dt, s->above, s->comm, stream)); }
+        for (int f : kHaloFromBelow) { void *q = row(f, d->jte, n); note(g_rccl.Send(q, n, dt, s->above, s->comm, stream), "ncclSend"); }
     if (s->above >= 0)
-        for (int f : kHaloFromAbove) { void *q = row(f, d->jte + 1, n); AMT_NCCL(g_rccl.Recv(q, n, dt, s->above, s->comm, stream)); }
+        for (int f : kHaloFromAbove) { void *q = row(f, d->jte + 1, n); note(g_rccl.Recv(q, n, dt, s->above, s->comm, stream), "ncclRecv"); }
     if (s->below >= 0)
-        for (int f : kHaloFromBelow) { void *q = row(f, d->jts - 1, n); AMT_NCCL(g_rccl.Recv(q, n, dt, s->below, s->comm, stream)); }
-    AMT_NCCL(g_rccl.GroupEnd());
+        for (int f : kHaloFromBelow) { void *q = row(f, d->jts - 1, n); note(g_rccl.Recv(q, n, dt, s->below, s->comm, stream), "ncclRecv"); }
+    note(g_rccl.GroupEnd(), "ncclGroupEnd");
+    if (first != ncclSuccess)
+        return amt_fail(AMT_ERR_COMM, "%s failed in the halo exchange: %s", what,
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(first) : "?");
     return AMT_OK;
 }
 
@@ -324,3 +437,41 @@ extern "C" long amt_slab_halo_bytes(const amt_slab *s)
     return (long)(per_pair * d->dtype_bytes * ((s->below >= 0) + (s->above >= 0)));
 }
 
+
+// What the communicator itself says about this rank (ncclCommUserRank / ncclCommCount): a bench
+// line can then show that `world` ranks really joined.  Without a communicator: 0 of 1.
+extern "C" int amt_slab_comm_info(const amt_slab *s, int *rank, int *world)
+{
+    if (!s) return amt_fail(AMT_ERR_INVALID_ARG, "null slab");
+    int r = 0, w = 1;
+    if (s->comm) {
+        AMT_NCCL(g_rccl.CommUserRank(s->comm, &r));
+        AMT_NCCL(g_rccl.CommCount(s->comm, &w));
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
+    return AMT_OK;
+}
+
+// max over the ranks of *x (in place); also a barrier: every rank's streams are drained first and
+// nobody returns before all have contributed.  For reporting only (the max-over-ranks sweep time
+// of a host without MPI) -- the sweep itself uses no collective.
+extern "C" int amt_slab_max(amt_slab *s, double *x)
+{
+    if (!s || !x) return amt_fail(AMT_ERR_INVALID_ARG, "bad reduction argument");
+    DeviceScope scope(s->dom->device);
+    AMT_HIP(hipStreamSynchronize(s->dom->stream));
+    AMT_HIP(hipStreamSynchronize(s->comm_stream));
+    if (!s->comm || s->world == 1) return AMT_OK;
+    AMT_HIP(hipMemcpyAsync(s->red, x, sizeof(double), hipMemcpyHostToDevice, s->comm_stream));
+    AMT_NCCL(g_rccl.AllReduce(s->red, s->red, 1, ncclDouble, ncclMax, s->comm, s->comm_stream));
+    AMT_HIP(hipMemcpyAsync(x, s->red, sizeof(double), hipMemcpyDeviceToHost, s->comm_stream));
+    AMT_HIP(hipStreamSynchronize(s->comm_stream));
+    return AMT_OK;
+}
+
+extern "C" int amt_slab_barrier(amt_slab *s)
+{
+    double zero = 0.0;
+    return amt_slab_max(s, &zero);
+}

@@ -35,6 +35,9 @@ program advance_mu_t_slab_driver
   real(c_float) :: ms
   real(wp), allocatable, target :: mu(:,:)
   real(kind=8) :: cells, bytes
+  real(c_double) :: ms_job
+  integer(c_int) :: crank, cworld
+  integer(kind=8) :: c0, c1, crate
   integer :: n
 
   ni = 512; nk = 60; nj = 512; nsweeps = 20; loopback = 0
@@ -88,16 +91,26 @@ program advance_mu_t_slab_driver
         cpath(n) = path(n:n)
      end do
      cpath(len_trim(path) + 1) = c_null_char
-     call amt_check(amt_comm_rendezvous_file(cpath, int(rank, c_int), 120.0_c_double, uid), 'amt_comm_rendezvous_file')
+     ! nonce 0: derived from the launcher (run id, parent process), so that a file left by an
+     ! earlier launch on the same port is never taken for this one's
+     call amt_check(amt_comm_rendezvous_file(cpath, 0_c_int64_t, int(rank, c_int), int(max(world, 1), c_int), &
+                                             120.0_c_double, uid), 'amt_comm_rendezvous_file')
      idptr = c_loc(uid)
      if (loopback /= 0) flags = 2                      ! AMT_SLAB_LOOPBACK
   end if
   call amt_check(amt_slab_create(slab, dom, int(rank, c_int), int(world, c_int), idptr, int(flags, c_int)), 'amt_slab_create')
 
   call amt_check(amt_slab_step(slab, 2_c_int), 'amt_slab_step (warm-up)')   ! code objects, RCCL connections
-  call amt_check(amt_slab_sync(slab), 'amt_slab_sync')
+  call amt_check(amt_slab_barrier(slab), 'amt_slab_barrier')                ! every rank starts the clock together
+  call system_clock(c0, crate)
   call amt_check(amt_slab_step_timed(slab, int(nsweeps, c_int), ms), 'amt_slab_step_timed')
   call amt_check(amt_slab_sync(slab), 'amt_slab_sync')
+  call system_clock(c1)
+  ! the sweep time of the JOB is the slowest rank's (a rank's own event time excludes the wait
+  ! for a late neighbour's halo only if that neighbour is late AFTER this rank has finished)
+  ms_job = real(c1 - c0, 8) * 1.0d3 / real(crate, 8)
+  call amt_check(amt_slab_max(slab, ms_job), 'amt_slab_max')
+  call amt_check(amt_slab_comm_info(slab, crank, cworld), 'amt_slab_comm_info')
 
   cells = real(ni, 8) * real(nk, 8) * real(jhi - jlo + 1, 8)
   bytes = real(storage_size(1.0_wp)/8, 8) * real(ni, 8) * real(jhi - jlo + 1, 8) * (11.0d0 * nk + 14.0d0)
@@ -108,6 +121,11 @@ program advance_mu_t_slab_driver
         ms / nsweeps, ' ms/sweep ', cells * nsweeps / (ms * 1.0d-3) / 1.0d6, ' Mcells/s ',            &
         bytes * nsweeps / (ms * 1.0d-3) / 1.0d9, ' GB/s algorithmic; halo bytes/sweep ',              &
         amt_slab_halo_bytes(slab), '; sum(mu) ', sum(real(mu(1:ni, jlo:jhi), 8))
+  if (rank == 0) then
+     cells = real(ni, 8) * real(nk, 8) * real(nj, 8)
+     print '(a,i0,a,f9.4,a,f11.1,a)', 'job: ', cworld, ' rank(s) in the communicator, slowest rank ', &
+           ms_job / nsweeps, ' ms/sweep wall = ', cells * nsweeps / (ms_job * 1.0d-3) / 1.0d6, ' Mcells/s'
+  end if
 
   call amt_check(amt_slab_destroy(slab), 'amt_slab_destroy')
   call amt_check(amt_domain_destroy(dom), 'amt_domain_destroy')

@@ -139,10 +139,12 @@ MODULE amt_c_binding
          integer(c_int), value :: device
          integer(c_int) :: rc
       end function
-      function amt_comm_rendezvous_file(path, rank, timeout_s, id_out) bind(C, name="amt_comm_rendezvous_file") result(rc)
-         import :: c_char, c_int, c_double
+      function amt_comm_rendezvous_file(path, nonce, rank, world, timeout_s, id_out)              &
+            bind(C, name="amt_comm_rendezvous_file") result(rc)
+         import :: c_char, c_int, c_double, c_int64_t
          character(kind=c_char), intent(in) :: path(*)      ! NUL-terminated
-         integer(c_int), value :: rank
+         integer(c_int64_t), value :: nonce                 ! 0: amt_comm_launch_nonce()
+         integer(c_int), value :: rank, world
          real(c_double), value :: timeout_s
          character(kind=c_char), intent(out) :: id_out(128)
          integer(c_int) :: rc
@@ -181,6 +183,23 @@ MODULE amt_c_binding
          import :: c_ptr, c_long
          type(c_ptr), value :: slab
          integer(c_long) :: n
+      end function
+      function amt_slab_comm_info(slab, rank, world) bind(C, name="amt_slab_comm_info") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: slab
+         integer(c_int) :: rank, world
+         integer(c_int) :: rc
+      end function
+      function amt_slab_barrier(slab) bind(C, name="amt_slab_barrier") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: slab
+         integer(c_int) :: rc
+      end function
+      function amt_slab_max(slab, x) bind(C, name="amt_slab_max") result(rc)
+         import :: c_ptr, c_int, c_double
+         type(c_ptr), value :: slab
+         real(c_double) :: x                                 ! in: this rank's value, out: the maximum
+         integer(c_int) :: rc
       end function
 
       ! (4) synthetic inputs

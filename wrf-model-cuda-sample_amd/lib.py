@@ -53,11 +53,14 @@ SYMBOLS = {
     "amt_advance_mu_t_device_f64": (_I, _adv_sig(ctypes.c_double, True)),
     "amt_compute_window": (_I, [_I] * 13 + [ctypes.POINTER(_I)] * 6),
     "amt_domain_create": (_I, [ctypes.POINTER(_P), _I] + [_I] * 20),
+    "amt_domain_wrap": (_I, [ctypes.POINTER(_P), _I] + [_I] * 20 + [ctypes.POINTER(_P), _P]),
     "amt_domain_destroy": (_I, [_P]),
     "amt_domain_set_scalars": (_I, [_P] + [ctypes.c_double] * 4),
     "amt_domain_set_variant": (_I, [_P, _I]),
     "amt_domain_upload": (_I, [_P, _I, _P]),
     "amt_domain_download": (_I, [_P, _I, _P]),
+    "amt_domain_upload_rows": (_I, [_P, _I, _I, _I, _P]),
+    "amt_domain_download_rows": (_I, [_P, _I, _I, _I, _P]),
     "amt_domain_fill_synthetic": (_I, [_P, ctypes.c_uint64] + [_L] * 6),
     "amt_domain_step": (_I, [_P, _I]),
     "amt_domain_step_timed": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
@@ -72,7 +75,8 @@ SYMBOLS = {
     "amt_host_release": (_I, []),
     "amt_set_device": (_I, [_I]),
     "amt_comm_unique_id": (_I, [_P]),
-    "amt_comm_rendezvous_file": (_I, [ctypes.c_char_p, _I, ctypes.c_double, _P]),
+    "amt_comm_rendezvous_file": (_I, [ctypes.c_char_p, ctypes.c_uint64, _I, _I, ctypes.c_double, _P]),
+    "amt_comm_launch_nonce": (ctypes.c_uint64, []),
     "amt_slab_create": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P, _I]),
     "amt_slab_destroy": (_I, [_P]),
     "amt_slab_exchange": (_I, [_P]),
@@ -80,6 +84,9 @@ SYMBOLS = {
     "amt_slab_step_timed": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
     "amt_slab_sync": (_I, [_P]),
     "amt_slab_halo_bytes": (_L, [_P]),
+    "amt_slab_comm_info": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "amt_slab_barrier": (_I, [_P]),
+    "amt_slab_max": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
 }
 
 

@@ -262,3 +262,107 @@ class GridStepper:
             self._call()
         else:
             self.compute(*args)
+
+
+class NativeSlabStepper:
+    """The same j-slab sweep as ``SlabStepper`` driven by the C++ runtime behind the C-ABI
+    (``amt_slab_*``, include/amt_advance_mu_t.h section 5): ``ncclSend/ncclRecv`` of the halo rows
+    in one RCCL group on a communication stream, the two edge rows behind them on that stream, the
+    interior on the patch's stream.  This is the path a Fortran or C host calls
+    (fortran/advance_mu_t_slab_driver.f90); Python only hands over pointers.
+
+    ``patch`` holds torch CUDA tensors (they stay the owners: ``amt_domain_wrap``); ``stream`` is
+    the torch stream the sweeps are enqueued on; ``unique_id`` are the AMT_UNIQUE_ID_BYTES every rank
+    got from rank 0's ``comm_unique_id()`` (None when world == 1 and not loopback).
+    Creating it is collective over the ``world`` ranks (ncclCommInitRank).
+    """
+
+    NO_OVERLAP, LOOPBACK = 1, 2          # enum amt_slab_flags
+
+    def __init__(self, patch: Patch, rank: int, world: int, unique_id: Optional[bytes] = None, *,
+                 stream=None, overlap: bool = True, variant: int = 0, loopback: bool = False):
+        import ctypes
+        import torch
+        from . import lib as _lib
+        from .synth import FIELD_NAMES
+        self._lib, self._ct = _lib, ctypes
+        self.L = L = _lib.load_library()
+        self.patch, self.rank, self.world = patch, rank, world
+        self.below: Optional[int] = rank - 1 if rank > 0 else None
+        self.above: Optional[int] = rank + 1 if rank < world - 1 else None
+        t0 = patch.arrays["t_1"]
+        if not t0.is_cuda:
+            raise TypeError("NativeSlabStepper needs a device patch (there is no CPU path)")
+        b = patch.bounds
+        for name in FIELD_NAMES:
+            t = patch.arrays[name]
+            if not (t.is_cuda and t.dtype == t0.dtype and t.is_contiguous() and tuple(t.shape) == tuple(b.shape(name))):
+                raise TypeError(f"{name}: need a contiguous device tensor of shape {b.shape(name)}")
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=t0.device)
+        self.device_index = t0.device.index if t0.device.index is not None else torch.cuda.current_device()
+        fields = (ctypes.c_void_p * len(FIELD_NAMES))(*[patch.arrays[n].data_ptr() for n in FIELD_NAMES])
+        self._dom, self._slab = ctypes.c_void_p(), ctypes.c_void_p()
+        with torch.cuda.device(self.device_index):
+            _lib.check(L.amt_domain_wrap(ctypes.byref(self._dom), t0.element_size(), *patch.config.as_ints(),
+                                         *b.as_tuple(), fields, ctypes.c_void_p(self.stream.cuda_stream)))
+            try:
+                _lib.check(L.amt_domain_set_scalars(self._dom, patch.rdx, patch.rdy, patch.dts, patch.epssm))
+                _lib.check(L.amt_domain_set_variant(self._dom, int(variant)))
+                flags = (0 if overlap else self.NO_OVERLAP) | (self.LOOPBACK if loopback else 0)
+                uid = None
+                if unique_id is not None:
+                    uid = (ctypes.c_char * 128).from_buffer_copy(bytes(unique_id))
+                _lib.check(L.amt_slab_create(ctypes.byref(self._slab), self._dom, rank, world, uid, flags))
+            except BaseException:
+                L.amt_domain_destroy(self._dom)
+                self._dom = ctypes.c_void_p()
+                raise
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: a fresh communicator id to hand to every rank (ncclGetUniqueId)."""
+        import ctypes
+        from . import lib as _lib
+        uid = (ctypes.c_char * 128)()
+        _lib.check(_lib.load_library().amt_comm_unique_id(uid))
+        return bytes(uid)
+
+    def _dev(self):
+        import torch
+        return torch.cuda.device(self.device_index)
+
+    def step(self, n_sweeps: int = 1):
+        with self._dev():
+            self._lib.check(self.L.amt_slab_step(self._slab, int(n_sweeps)))
+
+    def exchange_halos(self):
+        with self._dev():
+            self._lib.check(self.L.amt_slab_exchange(self._slab))
+
+    def sync(self):
+        with self._dev():
+            self._lib.check(self.L.amt_slab_sync(self._slab))
+
+    def halo_bytes_per_sweep(self) -> int:
+        return 2 * int(self.L.amt_slab_halo_bytes(self._slab))       # sent + received
+
+    def comm_info(self):
+        """(rank, world) as the RCCL communicator reports them; (0, 1) without one."""
+        r, w = self._ct.c_int(), self._ct.c_int()
+        self._lib.check(self.L.amt_slab_comm_info(self._slab, self._ct.byref(r), self._ct.byref(w)))
+        return r.value, w.value
+
+    def close(self):
+        if self._slab:
+            with self._dev():
+                self.L.amt_slab_destroy(self._slab)
+            self._slab = self._ct.c_void_p()
+        if self._dom:
+            self.L.amt_domain_destroy(self._dom)
+            self._dom = self._ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
