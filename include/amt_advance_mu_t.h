@@ -300,6 +300,19 @@ int amt_slab_max(amt_slab *slab, double *x);
 int amt_calib_stream_copy(void *hip_stream, void *dst_device, const void *src_device,
                           size_t nbytes, int bytes_per_lane);
 
+/* ------------------------------------------------------------------------
+ * (7) Tuning and test hooks of AMT_VARIANT_MARCH: force the wave shape
+ *     (columns per lane, levels per lane, level groups per wave, extra DMA'd inputs, DMA or
+ *     register flavour, rows per workgroup, 16- or 11-wave build; 0 / -1 = leave it to the launcher) for every later
+ *     call of the process -- a shape that cannot run the given level count makes the call fail
+ *     (AMT_VARIANT_AUTO then falls back to the column kernel).  amt_march_last_kernel names the
+ *     instantiation the calling thread's last plan chose; amt_march_selectable lists the ones the
+ *     launcher can choose unforced, one per line (returns the bytes needed).
+ * ------------------------------------------------------------------------ */
+int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, int jrows, int max_waves);
+const char *amt_march_last_kernel(void);
+int amt_march_selectable(char *buf, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,9 @@ SYMBOLS = {
     "amt_slab_comm_info": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "amt_slab_barrier": (_I, [_P]),
     "amt_slab_max": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
+    "amt_march_force_shape": (_I, [_I] * 7),
+    "amt_march_last_kernel": (ctypes.c_char_p, []),
+    "amt_march_selectable": (_I, [ctypes.c_char_p, _I]),
 }
 
 
@@ -99,6 +102,13 @@ def load_library() -> ctypes.CDLL:
         if not path.exists():
             raise AmtError(ERR_NO_DEVICE, f"{path} not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                                           "(make -C wrf-model-cuda-sample_amd/csrc); there is no CPU fallback")
+        try:
+            # one HIP runtime per process: torch ships its own libamdhip64.so.7 and must bring it in
+            # before this library resolves the same SONAME from /opt/rocm (otherwise torch ends up on
+            # a runtime its other bundled libraries do not match: "no ROCm-capable device")
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(str(path))
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)
