@@ -23,6 +23,8 @@
  *  - Preconditions (anything else is undefined in the Fortran as well, see
  *    DESIGN.md): kts == 1, kte == kde, kms <= 1, kme >= kte, and the compute
  *    window plus its one-cell input halo (i-1, i+1, j-1, j+1) inside memory.
+ *    Level count: a column's k chains live in LDS, which holds 320 levels in
+ *    fp64 and 640 in fp32 (AMT_ERR_PRECONDITION beyond; WRF runs 30..150).
  *  - Return value: AMT_OK or an amt_status code; nothing ever calls exit()
  *    (the reference's wrapper prints and exit(1)s, advance_mu_t_no_async.cu:22-32,
  *    82-85).  amt_last_error() gives the text for the calling thread.

@@ -1,0 +1,105 @@
+"""Parity at BASELINE.json's full sizes, anchored on the oracle rather than on cross-kernel agreement
+(VERDICT r01 "weak" 6 and "missing" 3):
+
+* configs[2], 4096 x 60 x 4096 fp64 (82 GB resident): more than 10 % of the rows of one sweep are
+  recomputed by the oracle -- 64-row j chunks from regenerated inputs, OpenMP j-tiles on all host
+  cores -- among them both domain edges and chunks that straddle the workgroups' j-block boundaries.
+* configs[4]'s "async H2D/D2H": the streamed one-shot drop-in on a domain that needs many chunks
+  (2048 x 80 x 2048 fp32, 13.6 GB of host arrays), pageable and page-locked, against the oracle.
+"""
+import ctypes
+import os
+import re
+import time
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def test_tenth_of_the_rows_of_configs2_against_the_oracle(pkg, oracle):
+    import torch
+    S = pkg.synth
+    L = pkg.load_library()
+    dims = (4096, 60, 4096)
+    b = S.domain_bounds(*dims, aligned=True)
+    need = 10 * b.idim * b.kdim * b.jdim * 8 * 1.05
+    if torch.cuda.mem_get_info(0)[0] < need:
+        pytest.skip(f"needs {need / 1e9:.0f} GB of free HBM")
+    cfg = pkg.GridConfig(specified=True)
+    dev = S.make_patch(b, cfg, dtype=np.float64, seed=4242, device="cuda:0")
+    pkg.advance_mu_t(*dev.args())
+    torch.cuda.synchronize()
+    m = re.search(r"jrows=(\d+)", L.amt_march_last_kernel().decode())
+    jrows = int(m.group(1)) if m else 32
+    t0 = time.time()
+    rows = 64
+    # chunk starts: both domain edges, and chunks whose middle is a j-block boundary (first rows of
+    # a workgroup's block come out of its prologue, the last ones end its march)
+    first_row = 2                                              # specified: j_start = jds + 1
+    bnd = [first_row + jrows * k for k in (1, 17, 40, 63, 90, 111)]
+    starts = [1, dims[2] - rows + 1] + [x - rows // 2 for x in bnd if x + rows // 2 <= dims[2]]
+    threads = max(1, min(len(os.sched_getaffinity(0)), rows))
+    checked = set()
+    for jlo in starts:
+        jhi = jlo + rows - 1
+        sb = b.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
+        want = S.make_patch(sb, cfg, dtype=np.float64, seed=4242, global_dims=dims, device="cuda:0").to_host()
+        oracle.advance_mu_t_omp(*want.args(), nthreads=threads)
+        for n in S.OUTPUTS:
+            got = dev.arrays[n][jlo - b.jms: jhi + 1 - b.jms].cpu().numpy()
+            assert bits_equal(got, want.arrays[n][1:-1]), f"rows {jlo}..{jhi}: {n} differs from the oracle"
+        checked.update(range(jlo, jhi + 1))
+    assert len(checked) >= 0.10 * dims[2], len(checked)
+    assert time.time() - t0 < 90
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "page-locked"])
+def test_streamed_one_shot_on_a_many_chunk_domain(pkg, oracle, pinned):
+    """Host arrays in, host arrays out (advance_mu_t_no_async.cu:245-306, 366-390 done with three
+    streams): 2048 x 80 x 2048 fp32 goes up and comes down in ~45 chunks of 320 MB."""
+    import torch
+    S = pkg.synth
+    L = pkg.load_library()
+    dims = (2048, 80, 2048)
+    b = S.domain_bounds(*dims)
+    gb = 10 * b.idim * b.kdim * b.jdim * 4 / 1e9
+    if _host_gb() < 3.2 * gb + 8:
+        pytest.skip(f"needs {3.2 * gb + 8:.0f} GB of host memory")
+    cfg = pkg.GridConfig(nested=True)
+    host = S.make_patch(b, cfg, dtype=np.float32, seed=99, global_dims=dims, device="cuda:0").to_host()
+    torch.cuda.empty_cache()
+    want = host.copy()
+    threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+    oracle.advance_mu_t_omp(*want.args(), nthreads=threads)
+    pins = []
+    try:
+        if pinned:
+            for n in S.RANK3:
+                a = host.arrays[n]
+                pkg.lib.check(L.amt_host_pin(a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+                pins.append(a)
+        t0 = time.time()
+        pkg.advance_mu_t(*host.args())
+        dt = time.time() - t0
+    finally:
+        for a in pins:
+            L.amt_host_unpin(a.ctypes.data_as(ctypes.c_void_p))
+        L.amt_host_release()
+    for n in S.FIELD_NAMES:
+        assert bits_equal(host.arrays[n], want.arrays[n]), n
+    assert dt < 60, dt

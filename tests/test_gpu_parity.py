@@ -427,11 +427,14 @@ def test_full_size_slab_properties(pkg, oracle, torch_mod):
 
 
 @pytest.mark.parametrize("dims,dtype", [((4096, 60, 1024), np.float64), ((4096, 60, 4096), np.float64),
-                                        ((8192, 80, 2048), np.float32)],
-                         ids=["quarter-f64", "configs2-4096x60x4096-f64", "configs4-quarter-8192x80-f32"])
+                                        ((8192, 80, 2048), np.float32), ((8192, 80, 8192), np.float32)],
+                         ids=["quarter-f64", "configs2-4096x60x4096-f64", "configs4-quarter-8192x80-f32",
+                              "configs4-8192x80x8192-f32"])
 def test_large_domain_checksums_agree_across_kernels(pkg, oracle, torch_mod, dims, dtype):
     """Every cell of a large domain -- a quarter of BASELINE.json configs[2] (21 GB), configs[2]
-    itself (4096 x 60 x 4096 fp64, 82 GB resident) and a quarter of configs[4] (8192 x 80 fp32):
+    itself (4096 x 60 x 4096 fp64, 82 GB resident), a quarter of configs[4] and configs[4] itself
+    (8192 x 80 x 8192 fp32, 219 GB resident; there the fp32 result is also held against the fp64 oracle
+    at the stated tolerance):
     the production kernel in one launch, the same kernel swept as seven ragged j tiles (other block
     sizes, other prologues) and the simple column kernel must leave bit-identical outputs -- compared
     through wrap-around integer checksums of the raw bit patterns -- and a few slabs are anchored to
@@ -462,6 +465,15 @@ def test_large_domain_checksums_agree_across_kernels(pkg, oracle, torch_mod, dim
         for n in S.OUTPUTS:
             got = dev.arrays[n][jlo - b.jms: jlo + 3 - b.jms].cpu().numpy()
             assert bits_equal(got, want.arrays[n][1:4]), (jlo, n)
+        if dtype == np.float32:
+            # BASELINE.json configs[4]: the fp32 run against the fp64 Fortran, per output array
+            # max|fp32 - fp64| <= 2e-5 * max|fp64|  (FP32_VS_FP64_TOL below)
+            w64 = S.make_patch(sb, pkg.GridConfig(specified=True), dtype=np.float64, seed=77, global_dims=dims)
+            oracle.advance_mu_t_omp(*w64.args(), nthreads=3)
+            for n in S.OUTPUTS:
+                got = dev.arrays[n][jlo - b.jms: jlo + 3 - b.jms].cpu().numpy().astype(np.float64)
+                ref = w64.arrays[n][1:4]
+                assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (jlo, n)
     del dev
     torch.cuda.empty_cache()
     dev, tiled = run(pkg.VARIANT_MARCH, 7)        # ragged j tiles: other block sizes, other prologues
@@ -472,3 +484,36 @@ def test_large_domain_checksums_agree_across_kernels(pkg, oracle, torch_mod, dim
     assert column == auto
     del dev
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("nk", [61, 76, 80, 88, 100, 120, 128, 133, 176, 200, 264, 300])
+def test_many_levels_match_oracle(pkg, oracle, torch_mod, nk, dtype):
+    """Level counts beyond the 60 of BASELINE.json (61..90 ran spilling kernels, beyond
+    that the column kernel): whatever the launcher picks -- level groups of 2 or 4 per wave, 12- or
+    16-wave builds, the column kernel past 264 levels -- against the oracle, aligned (LDS-DMA) and
+    unaligned (register flavour) layouts; the column kernel alone as well (its LDS column passes
+    64 KB at 129 levels in fp64)."""
+    S = pkg.synth
+    L = pkg.load_library()
+    for aligned in (True, False):
+        b = S.domain_bounds(150, nk, 5, aligned=aligned)
+        host = S.make_patch(b, pkg.GridConfig(specified=True), dtype=dtype, seed=nk, global_dims=(150, nk, 5))
+        want = host.copy()
+        oracle.advance_mu_t(*want.args())
+        for variant in (pkg.VARIANT_AUTO, pkg.VARIANT_COLUMN):
+            dev = host.to_device("cuda:0")
+            pkg.advance_mu_t(*dev.args(), variant=variant)
+            torch_mod.cuda.synchronize()
+            assert_patch_equal(pkg, dev.to_host(), want, f"nk={nk} aligned={aligned} variant={variant} "
+                                                         f"({L.amt_march_last_kernel().decode()})")
+
+
+def test_level_count_beyond_lds_is_refused(pkg, torch_mod):
+    S = pkg.synth
+    b = S.domain_bounds(64, 330, 3, aligned=True)
+    dev = S.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=1, device="cuda:0")
+    with pytest.raises(pkg.AmtError) as e:
+        pkg.advance_mu_t(*dev.args())
+    assert e.value.status == 2
+    torch_mod.cuda.synchronize()

@@ -128,6 +128,9 @@ static int amt_launch(hipStream_t stream, int variant, const AmtParams<T> &p)
         variant = amt_march_supported(p) ? AMT_VARIANT_MARCH : AMT_VARIANT_COLUMN;
     hipError_t e;
     if (variant == AMT_VARIANT_COLUMN) {
+        if ((size_t)p.nk * 64 * sizeof(T) > 160 * 1024)
+            return amt_fail(AMT_ERR_PRECONDITION, "nk=%d: no kernel holds a column of more than %d levels in LDS",
+                            p.nk, (int)(160 * 1024 / (64 * sizeof(T))));
         e = amt_launch_column<T>(stream, p);
     } else if (variant == AMT_VARIANT_MARCH) {
         if (!amt_march_supported(p))

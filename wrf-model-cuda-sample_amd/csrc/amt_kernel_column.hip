@@ -123,6 +123,20 @@ hipError_t amt_launch_column(hipStream_t stream, const AmtParams<T> &p)
     q.msfvx_inv += shift; q.msftx += shift; q.msfty += shift;
     q.i0 -= (int)shift; q.i1 -= (int)shift;
     const size_t lds = (size_t)(p.nk > 0 ? p.nk : 1) * 64 * sizeof(T);
+    // one dvdxi column per lane in LDS: 160 KB hold 320 levels in fp64, 640 in fp32
+    if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
+    if (lds > 64 * 1024) {
+        // beyond 64 KB of dynamic LDS a kernel has to be allowed to (per device, once)
+        static unsigned granted = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!(granted >> (dev & 31) & 1u)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_column_kernel<T>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            granted |= 1u << (dev & 31);
+        }
+    }
     const unsigned grid = (unsigned)((long)ntile_i * nj);
     hipLaunchKernelGGL(amt_column_kernel<T>, dim3(grid), dim3(64), lds, stream, q, ntile_i);
     return hipGetLastError();

@@ -943,6 +943,29 @@ extern "C" int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, i
     return 0;
 }
 
+// Rows per workgroup.  A block costs its rows plus a prologue (4 extra array-rows of loads, about
+// half a row of time); workgroups run in rounds of one per CU (two small workgroups that share a CU
+// each run slower than one with twice the rows: 128x60x128 fp64 28 us against 23), so the sweep takes
+// about  rounds(r) * (r + 0.5)  row-times.  The r that minimises it: for the whole 4096-row domain any
+// r near 32 is within 1 %, but for a 510-row j-slab (8 GPUs) r = 32 would leave the last round 6 %
+// full (1040 workgroups on 256 CUs) and cost 17 % more than r = 11.  Small launches get short blocks,
+// down to one row (more workgroups: 64x40x64 takes 12 us with r = 1, 27 us with r = 4).
+static int amt_march_rows(long ntile_i, int nj, int cus, double *cost_out, long *rounds_out)
+{
+    double best = 1e300;
+    int jrows = 1;
+    long brounds = 1;
+    for (int r = 1; r <= 64 && r <= nj; ++r) {
+        const long blocks = ntile_i * ((nj + r - 1) / r);
+        const long rounds = (blocks + cus - 1) / cus;
+        const double cost = (double)rounds * (r + 0.5);
+        if (cost < best - 1e-9 || (cost < best + 1e-9 && r > jrows)) { best = cost; jrows = r; brounds = rounds; }
+    }
+    if (cost_out) *cost_out = best;
+    if (rounds_out) *rounds_out = brounds;
+    return jrows;
+}
+
 // Shape preference.  Measured (profiles/r02_shapes.md): most waves to hide latency and fewest
 // registers per lane first -- 4 levels per lane is what fits 127 VGPRs in fp64 (and in fp32 with two
 // columns per lane) without scratch; more levels come from splitting the wave into level groups
@@ -992,8 +1015,34 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
             }
         return false;                                               // a forced shape that cannot run is an error, not a fallback
     }
-    for (int i = 0; i < npref; ++i)
-        if (usable(pref[i])) { out = pref[i]; return true; }
+    for (int i = 0; i < npref; ++i) {
+        if (!usable(pref[i])) continue;
+        out = pref[i];
+        // Patch-sized launches (WRF patches are a few hundred columns wide): a launch that fits one
+        // round of workgroups is latency-bound, and a tile half as wide -- twice the level groups,
+        // twice the workgroups -- makes every row of a workgroup cost about 0.8 of the wide one's
+        // (profiles/r02_small_domains.md: 64x40x64 11 -> 9 us, 128x60x128 fp64 30 -> 23 us), while in
+        // a launch of several rounds it moves fewer bytes per second (512x60x512: 1.17x the time).
+        {
+            const int nj = p.j1 - p.j0 + 1, cus = 256;
+            auto model = [&](const AmtMarchShape &q) {
+                const int tc = (64 / q.hl) * q.vw;
+                double c = 0;
+                long rounds = 1;
+                amt_march_rows(p.i1 / tc - p.i0 / tc + 1, nj, cus, &c, &rounds);
+                return c * (q.hl == out.hl ? 1.0 : rounds == 1 ? 0.8 : 1.2);
+            };
+            if (out.hl < 4)
+                for (int k = i + 1; k < npref; ++k) {
+                    const AmtMarchShape &q = pref[k];
+                    if (q.vw == out.vw && q.dma == out.dma && q.hl == 2 * out.hl && usable(q)) {
+                        if (model(q) < model(out) - 1e-9) out = q;
+                        break;
+                    }
+                }
+        }
+        return true;
+    }
     return false;
 }
 
@@ -1050,27 +1099,8 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
     const int nj = p.j1 - p.j0 + 1;
     g.tile_lo = p.i0 / tc;
     g.ntile_i = p.i1 / tc - g.tile_lo + 1;
-    // Rows per workgroup.  A block costs its rows plus a prologue (4 extra array-rows of loads,
-    // about half a row of time); workgroups run in rounds of `slots` = CUs x resident
-    // workgroups per CU, so the sweep takes about  rounds(r) * (r + 0.5)  row-times.  Pick the r
-    // that minimises it: for the whole 4096-row domain any r near 32 is within 1 %, but for a
-    // 510-row j-slab (8 GPUs) r = 32 would leave the last round 6 % full (1040 workgroups on 256
-    // CUs) and cost 17 % more than r = 11.  Small launches get short blocks, down to one row (more
-    // workgroups: 64x40x64 takes 12 us with r = 1, 27 us with r = 4).
     int jrows = env.jrows;
-    if (jrows < 1) {
-        int per_cu = (int)((160u * 1024u) / (pl.lds ? pl.lds : 1));              // LDS bounds residency ...
-        const int by_waves = 32 / pl.nw;                                         // ... and so do the 32 waves of a CU
-        if (per_cu > by_waves) per_cu = by_waves;
-        const long sl = (long)amt_march_cus(pl.dev) * (per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu);
-        double best = 1e300;
-        for (int r = 1; r <= 64 && r <= nj; ++r) {
-            const long blocks = (long)g.ntile_i * ((nj + r - 1) / r);
-            const long rounds = (blocks + sl - 1) / sl;
-            const double cost = (double)rounds * (r + 0.5);
-            if (cost < best - 1e-9 || (cost < best + 1e-9 && r > jrows)) { best = cost; jrows = r; }
-        }
-    }
+    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), nullptr, nullptr);
     if (jrows > nj) jrows = nj;
     if (jrows > max_rows) jrows = (int)max_rows;
     g.jrows = jrows;
