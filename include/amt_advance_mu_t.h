@@ -77,8 +77,9 @@ int amt_device_count(void);               /* number of visible HIP devices, 0 if
  *     download, free -- on the current HIP device.  Of ww, t and t_ave only the
  *     cells the Fortran assigns (i_start..i_end, 1..kte-1, j_start..j_end) are
  *     written back; t_ave and the levels above 1 of ww are outputs only and are
- *     not uploaded.  The 2-D outputs come back as whole rows j_start..j_end
- *     with their cells outside i_start..i_end unchanged.
+ *     not uploaded.  Of the 2-D outputs, too, only the window's cells are written
+ *     back: host threads that run tiles of one domain concurrently (OpenMP tiles,
+ *     split in i or in j) never touch each other's cells.
  * ------------------------------------------------------------------------ */
 int amt_advance_mu_t_f32(
     float *ww, const float *ww_1, const float *u, const float *u_1,

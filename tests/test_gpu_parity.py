@@ -164,6 +164,39 @@ def test_one_shot_from_concurrent_host_threads(pkg, oracle):
     assert_patch_equal(pkg, p, want, "four concurrent tile threads")
 
 
+@pytest.mark.parametrize("pack", ["1", "0"], ids=["packed", "per-array"])
+def test_one_shot_from_threads_on_tiles_split_in_i(pkg, oracle, monkeypatch, pack):
+    """tiles that split i share their j rows.  The 2-D outputs come back as the window's
+    cells only in every regime (staged scatter, or a strided copy per array when AMT_STREAM_PACK=0 /
+    pinned small arrays), so a thread never rewrites a neighbour tile's freshly computed columns
+    with the values it uploaded.  Repeated to give the race a chance."""
+    import threading
+    monkeypatch.setenv("AMT_STREAM_PACK", pack)
+    S = pkg.synth
+    b = S.domain_bounds(200, 12, 40)
+    for rep in range(6):
+        p = S.make_patch(b, pkg.GridConfig(), seed=300 + rep)
+        want = p.copy()
+        oracle.advance_mu_t(*want.args())
+        errors = []
+
+        def tile(its, ite):
+            try:
+                pkg.advance_mu_t(*p.with_bounds(its=its, ite=ite).args())
+            except Exception as e:                      # noqa: BLE001
+                errors.append(e)
+
+        edges = [1, 37, 101, 150, b.ide + 1]
+        threads = [threading.Thread(target=tile, args=(edges[n], edges[n + 1] - 1)) for n in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        assert_patch_equal(pkg, p, want, f"four concurrent i-tiles, rep {rep}")
+    pkg.load_library().amt_host_release()
+
+
 def test_streamed_one_shot_with_pinned_host_arrays(pkg, oracle):
     """amt_host_pin on the ten 3-D arrays switches the one-shot call to the chunked three-stream
     pipeline (default chunk size); results must not change."""

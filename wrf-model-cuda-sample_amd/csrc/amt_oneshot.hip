@@ -274,13 +274,6 @@ static int amt_host_call(const AmtArgs<T> &h)
         if (pack_small) memcpy(staged(dev[0][f]), src, n * sizeof(T));
         else AMT_HIP(hipMemcpyAsync(dev[0][f], src, n * sizeof(T), hipMemcpyHostToDevice, up));
     }
-    if (!pack_small)                                          // whole-row downloads: keep the other cells' bits
-        for (int f = 0; f < 26; ++f) {
-            const Item &it = items[f];
-            if (it.rank != 2 || it.in) continue;
-            AMT_HIP(hipMemcpyAsync(dev[0][f], it.host + (size_t)(w.j_start - 1 - h.jms) * r2, r2 * wrow * sizeof(T),
-                                   hipMemcpyHostToDevice, up));
-        }
     if (pack_small && !pack_big)
         AMT_HIP(hipMemcpyAsync(ws.arena + small_begin, stage, arena_end - small_begin, hipMemcpyHostToDevice, up));
 
@@ -443,8 +436,11 @@ static int amt_host_call(const AmtArgs<T> &h)
             for (int f = 0; f < 26; ++f) {
                 const Item &it = items[f];
                 if (!it.out || it.rank != 2) continue;
-                AMT_HIP(hipMemcpyAsync(const_cast<T *>(it.host) + (size_t)(w.j_start - h.jms) * r2, dev[0][f] + r2,
-                                       (size_t)nj * r2 * sizeof(T), hipMemcpyDeviceToHost, down));
+                // the window's cells only (a strided copy): two host threads running tiles that split i
+                // must not rewrite each other's columns with what they uploaded
+                AMT_HIP(hipMemcpy2DAsync(const_cast<T *>(it.host) + (size_t)(w.j_start - h.jms) * r2 + p.i0, r2 * sizeof(T),
+                                         dev[0][f] + r2 + p.i0, r2 * sizeof(T), ni * sizeof(T), (size_t)nj,
+                                         hipMemcpyDeviceToHost, down));
             }
         }
     }
