@@ -120,54 +120,83 @@ def fp32_error_vs_fp64(pkg, oracle, dev, gb, dims, seed, rank_rows):
     return worst
 
 
+def host_cores():
+    """Threads worth running: the CPUs this process may use, capped by the cgroup's CPU quota (the GPU
+    boxes of this pool show 256 logical CPUs and grant 16 CPUs of time: beyond 16 threads the CFS
+    throttle makes a sweep slower, 2.7 Gcells/s at 16 threads against 0.25 at 256, profiles/r02_cpu_scaling.md)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} logical CPUs visible"
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < n:
+                note += f", cgroup cpu.max grants {q}"
+                n = q
+    except (OSError, ValueError):
+        pass
+    return n, note
+
+
 def cpu_baseline(pkg, oracle, dims, dtype, seed, rows, seconds):
-    """Oracle (C port of the Fortran), j-tiled over all host cores, on a j-slab sample."""
-    S = pkg.synth
+    """SURVEY.md section 8(d) / BASELINE.md section 4: the CPU restatement of the Fortran (oracle/, C,
+    `gcc -O3 -march=native -ffp-contract=off`: the checker's bits), timed at 64x40x64, 512x60x512 and on
+    a j-slab of the bench domain, on one thread and j-tiled over all host cores with OpenMP (the scheme
+    of advance_mu_t_driver.f90:175-209), every tile's pages first touched by the thread that computes it;
+    and the reference Fortran itself (oracle/_ref, one thread, INCLUDING its five whole-array debug
+    dumps per call, module_small_step_em.f90:175-189, written to /dev/null).  `value` is the slab run
+    on all cores.  Bounded: `seconds` caps every entry."""
     ni, nk, nj = dims
-    rows = max(1, min(rows, nj))
-    gb = S.domain_bounds(ni, nk, nj)
-    jlo = max(1, nj // 2 - rows // 2)
-    sb = gb.replace(jms=jlo - 1, jme=jlo + rows, jts=jlo, jte=jlo + rows - 1)
-    p = S.make_patch(sb, pkg.GridConfig(), dtype=dtype, seed=seed, global_dims=dims)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(cores, rows))
-    oracle.advance_mu_t_omp(*p.args(), nthreads=threads)           # warm
-    times = []
-    t_end = time.perf_counter() + seconds
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 200):
-        t0 = time.perf_counter()
-        oracle.advance_mu_t_omp(*p.args(), nthreads=threads)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    cells = ni * nk * rows
-    out = {"value": round(cells / med / 1e6, 2), "unit": "Mcells/s", "cores": threads, "kind": "port",
-           "sample": f"{ni}x{nk}x{rows} j-slab of the same synthetic domain, median of {len(times)} sweeps, "
-                     f"gcc -O2 OpenMP j-tiles ({threads} threads)",
-           "ms_per_sweep_sample": round(med * 1e3, 3)}
-    # single thread (the reference's own configuration: OpenMP commented out,
-    # advance_mu_t_driver.f90:175-209) on a shorter slab
-    r1 = max(1, min(8, rows))
-    s1 = gb.replace(jms=jlo - 1, jme=jlo + r1, jts=jlo, jte=jlo + r1 - 1)
-    p1 = S.make_patch(s1, pkg.GridConfig(), dtype=dtype, seed=seed, global_dims=dims)
-    oracle.advance_mu_t(*p1.args())
-    t1 = []
-    t_end = time.perf_counter() + min(3.0, seconds)
-    while len(t1) < 3 or (time.perf_counter() < t_end and len(t1) < 50):
-        t0 = time.perf_counter()
-        oracle.advance_mu_t(*p1.args())
-        t1.append(time.perf_counter() - t0)
-    out["one_thread_Mcells_s"] = round(ni * nk * r1 / float(np.median(t1)) / 1e6, 2)
-    # the reference Fortran itself (oracle/_ref, built from the reference's sources where they lie;
-    # its five debug dumps per call go to /dev/null), one thread, same short slab
+    cores, quota_note = host_cores()
+    slab_rows = max(1, min(nj, max(rows, 1024)))
+    budget = max(0.5, seconds / 6.0)                              # per entry
+    matrix = []
+
+    def run(shape, threads, what):
+        n_i, n_k, n_j = shape
+        threads = max(1, min(threads, n_j))
+        cells = n_i * n_k * n_j
+        est = cells / (150e6 * (threads ** 0.8))                  # rough seconds per sweep
+        reps = int(max(3, min(30, budget / max(est, 1e-4))))
+        ms, fill = oracle.bench(dtype, n_i, n_k, n_j, threads, reps, gj0=max(0, (nj - n_j) // 2), gnj=max(nj, n_j), seed=seed)
+        med = float(np.median(ms[1:] if len(ms) > 1 else ms))
+        rec = {"impl": "port_c_O3", "size": f"{n_i}x{n_k}x{n_j}" + (f" ({what})" if what else ""), "threads": threads,
+               "Mcells_s": round(cells / med / 1e3, 2), "ms_per_sweep": round(med, 4), "sweeps": len(ms)}
+        matrix.append(rec)
+        return rec
+
+    run((64, 40, 64), 1, "")
+    run((64, 40, 64), cores, "")
+    run((512, 60, 512), 1, "")
+    run((512, 60, 512), cores, "")
+    slab = run((ni, nk, slab_rows), cores, "j-slab of the bench domain, first touch by the computing thread")
+    out = {"value": slab["Mcells_s"], "unit": "Mcells/s", "cores": slab["threads"], "kind": "port",
+           "sample": f"{ni}x{nk}x{slab_rows} j-slab of the same synthetic domain, median of {slab['sweeps'] - 1} sweeps, "
+                     f"C restatement of the Fortran, gcc -O3 -march=native -ffp-contract=off, OpenMP j-tiles "
+                     f"({slab['threads']} threads), pages first touched by their tile's thread",
+           "ms_per_sweep_sample": slab["ms_per_sweep"],
+           "one_thread_Mcells_s": matrix[2]["Mcells_s"],
+           "host": quota_note,
+           "matrix": matrix}
+    # the reference Fortran itself (built from the reference's sources where they lie; oracle/_ref)
     if oracle.have_ref(np.dtype(dtype).itemsize):
-        p2 = S.make_patch(s1, pkg.GridConfig(), dtype=dtype, seed=seed, global_dims=dims)
-        oracle.ref_advance_mu_t(*p2.args())
-        t2 = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            oracle.ref_advance_mu_t(*p2.args())
-            t2.append(time.perf_counter() - t0)
-        out["reference_fortran_one_thread_Mcells_s"] = round(ni * nk * r1 / float(np.median(t2)) / 1e6, 2)
+        S = pkg.synth
+        for shape in ((64, 40, 64), (128, 60, 128)):
+            b = S.domain_bounds(*shape)
+            p2 = S.make_patch(b, pkg.GridConfig(), dtype=dtype, seed=seed, global_dims=shape)
+            t2 = []
+            t_end = time.perf_counter() + budget
+            while len(t2) < 2 or (time.perf_counter() < t_end and len(t2) < 10):
+                t0 = time.perf_counter()
+                oracle.ref_advance_mu_t(*p2.args())
+                t2.append(time.perf_counter() - t0)
+            matrix.append({"impl": "reference_fortran_incl_dumps", "size": "x".join(map(str, shape)), "threads": 1,
+                           "Mcells_s": round(np.prod(shape) / float(np.median(t2)) / 1e6, 2),
+                           "ms_per_sweep": round(float(np.median(t2)) * 1e3, 3), "sweeps": len(t2)})
+        out["reference_fortran_incl_dumps_one_thread_Mcells_s"] = matrix[-1]["Mcells_s"]
+        out["reference_note"] = ("amdflang -O2 -ffp-contract=off; every call writes five whole arrays (muave, mu, mudf, "
+                                 "muts, ww) as unformatted big-endian streams (here to /dev/null): that, not the "
+                                 "arithmetic, is most of its time")
     return out
 
 

@@ -75,6 +75,52 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+_bench_lib = None
+
+
+def bench_lib() -> ctypes.CDLL:
+    """The -O3 -march=native build with the timing driver (oracle_bench.c), compiled on THIS
+    machine (the in-tree liboracle_bench.so may come from another CPU)."""
+    global _bench_lib
+    if _bench_lib is None:
+        import hashlib
+        model = ""
+        try:
+            with open("/proc/cpuinfo") as f:
+                model = next((ln for ln in f if ln.startswith(("model name", "flags"))), "")
+                model += "".join(ln for ln in f if ln.startswith("flags"))[:4000]
+        except OSError:
+            pass
+        out = HERE / "_native" / hashlib.sha1(model.encode()).hexdigest()[:12] / "liboracle_bench.so"
+        if not out.exists() or out.stat().st_mtime < (HERE / "oracle_bench.c").stat().st_mtime:
+            subprocess.run(["make", "-C", str(HERE), f"BENCH_OUT={out}", str(out)], check=True, capture_output=True)
+        L = ctypes.CDLL(str(out))
+        L.oracle_bench.restype = ctypes.c_int
+        L.oracle_bench.argtypes = [ctypes.c_int] * 4 + [ctypes.c_long, ctypes.c_long, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                                        ctypes.POINTER(ctypes.c_double)]
+        for suffix, real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
+            f = getattr(L, f"oracle_advance_mu_t_{suffix}")
+            f.argtypes, f.restype = _sig(real), ctypes.c_int
+        _bench_lib = L
+    return _bench_lib
+
+
+def bench(dtype, ni, nk, nj, nthreads, reps, *, gj0=0, gnj=None, seed=12345):
+    """Timed sweeps of the -O3 restatement on a first-touch-correct NI x NK x NJ domain (a j-slab
+    starting at global row gj0 of a domain of gnj rows).  Returns (ms per sweep list, fill seconds)."""
+    L = bench_lib()
+    ms = (ctypes.c_double * reps)()
+    chk, fill = ctypes.c_double(), ctypes.c_double()
+    rc = L.oracle_bench(np.dtype(dtype).itemsize, ni, nk, nj, gj0, gnj if gnj is not None else nj, seed,
+                        nthreads, reps, ms, ctypes.byref(chk), ctypes.byref(fill))
+    if rc:
+        raise MemoryError(f"oracle_bench: status {rc}")
+    if not np.isfinite(chk.value):
+        raise ValueError("oracle_bench produced a non-finite checksum")
+    return list(ms), fill.value
+
+
 def have_ref(itemsize: int = 8) -> bool:
     return REF_PATHS[itemsize].exists()
 
