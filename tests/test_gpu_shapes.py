@@ -1,7 +1,7 @@
 """Every wave shape of AMT_VARIANT_MARCH the library carries -- columns per lane (VW), levels per
 lane (KPT), level groups per wave (HL), extra DMA'd inputs (XD), LDS-DMA or register flavour --
 forced through amt_march_force_shape and compared bit for bit with the oracle, on level counts that
-fill the cell waves and on ragged ones, aligned and unaligned layouts, all four flag combinations of
+fill the cell waves and on ragged ones, the aligned resident layout and minimal memory with odd row lengths, all four flag combinations of
 module_small_step_em.f90:97-106.  (The launcher's own choice is what every other test runs.)"""
 import numpy as np
 import pytest
@@ -64,11 +64,11 @@ def test_forced_shape_matches_oracle(pkg, oracle, force, shape):
     for n, nk in enumerate(_levels(kpt, hl)):
         cfg = pkg.GridConfig(**flags[n % 4])
         for aligned in (True, False):
-            if dma and not aligned:
-                continue                            # the DMA flavour needs 16-byte rows: the launcher would refuse
+            # unaligned: minimal memory, an ODD row length (ni + 2) whose last column is the window's
+            # i+1 neighbour -- the LDS-DMA takes it as it is (no alignment of the DMA source is needed)
             b = S.domain_bounds(ni, nk, 7, aligned=aligned)
-            if not aligned and vw == 2 and b.idim % 2:
-                b = b.replace(ime=b.ime + 1)        # two columns per lane need an even row length
+            if not aligned and vw == 2 and not dma and b.idim % 2:
+                b = b.replace(ime=b.ime + 1)        # register flavour with two columns per lane: even rows
             host = S.make_patch(b, cfg, dtype=dtype, seed=100 + nk, global_dims=(ni, nk, 7))
             want = host.copy()
             oracle.advance_mu_t(*want.args())

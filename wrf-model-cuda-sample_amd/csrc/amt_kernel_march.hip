@@ -350,6 +350,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         const int ii = tile * TC + c;
         const bool own = lane < TI;
         const bool inmem = own && (ii + VW <= p.idim);
+        const bool tail = VW > 1 && own && !inmem && ii < p.idim;  // odd row length: my first column is the row's last
         bool on[VW], any = false, all = true;
 #pragma unroll
         for (int e = 0; e < VW; ++e) {
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         for (int q = 0; q < N2D; ++q) {
             const T *src = d2_src(q);
             if (inmem) amt_stsv<T, VW>(D2 + q * TW + c, amt_ldv<T, VW>(src, vo));
+            if (tail) D2[q * TW + c] = amt_ld(src, vo);
             if (halo_r) D2[q * TW + TC] = amt_ld(src + TC, 0u);
         }
         __syncthreads();                           // S1, T1, TH, (VB ..), D2 staged
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             const bool more = (jj < jb);
             // while the cell waves do P1: fetch the next 2-D row and this row's column inputs
             V d2v[N2D];
-            T d2h[N2D];
+            T d2h[N2D];                                          // lane 0: the right halo; a tail lane: its one column
 #pragma unroll
             for (int q = 0; q < N2D; ++q) { d2v[q] = V(T(0)); d2h[q] = T(0); }
             if (more) {
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                     const T *src = d2_src(q);
                     if (inmem) d2v[q] = amt_ldv<T, VW>(src, o2 + row2);
                     if (halo_r) d2h[q] = amt_ld(src + TC, o2 - vo + row2);
+                    if (tail) d2h[q] = amt_ld(src, o2 + row2);
                 }
             }
             V ww1in(T(0)), mu_old(T(0)), mut_v(T(0)), mu_tend(T(0)), msfty_c(T(1));
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                 for (int q = 0; q < N2D; ++q) {
                     if (inmem) amt_stsv<T, VW>(D2 + q * TW + c, d2v[q]);
                     if (halo_r) D2[q * TW + TC] = d2h[q];
+                    if (tail) D2[q * TW + c] = d2h[q];
                 }
             }
             amt_lds_barrier();                                   // 2: DM published
@@ -792,13 +796,14 @@ static int amt_march_waves(const AmtMarchShape &s, int nk)
     return (nk + lw - 1) / lw + 1;                                 // cell waves + the column wave
 }
 
-// The LDS-DMA flavour moves 16-byte chunks: rows a multiple of 16 bytes, 16-byte aligned bases.
-template <typename T> static bool amt_march_dma_layout_ok(const AmtParams<T> &p)
+// The LDS-DMA flavour moves 16-byte chunks per lane, but `global_load_lds_dwordx4` needs no alignment
+// of its global SOURCE (measured on gfx950: sources shifted by 4, 8 or 12 bytes copy correctly and at
+// the aligned rate, 6.1-6.2 TB/s; profiles/r02_lds_dma_alignment.md), so any WRF layout -- odd row
+// lengths, arrays that start anywhere -- takes it.  A chunk that starts inside the memory row but runs
+// past its end reads on into the next level row of the same array (the levels fetched end below
+// kme >= kte, so there always is one) and fills LDS columns no lane uses.
+template <typename T> static bool amt_march_dma_layout_ok(const AmtParams<T> &)
 {
-    constexpr int EPL = 16 / (int)sizeof(T);
-    if (p.idim % EPL != 0) return false;
-    if ((reinterpret_cast<uintptr_t>(p.t_1) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.v_1)
-         | reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.u_1)) & 15u) return false;
     return true;
 }
 
@@ -992,7 +997,10 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
     const int npref = sizeof(T) == 8 ? (int)(sizeof pref64 / sizeof pref64[0]) : (int)(sizeof pref32 / sizeof pref32[0]);
     auto usable = [&](const AmtMarchShape &s) {
         if (s.dma && !dma_ok) return false;
-        if (s.vw > 1 && p.idim % s.vw != 0) return false;          // a lane's columns never straddle a row end
+        // two columns per lane on an odd row length: the last lane of a row straddles its end; it is never a
+        // window lane, its t_1 / v come by DMA chunks, its 2-D column is staged element-wise -- but the
+        // register flavour stages rows by lane vectors and needs an even length
+        if (s.vw > 1 && !s.dma && p.idim % s.vw != 0) return false;
         return amt_march_shape_feasible(wb, s, nk) && amt_march_find<T>(s) != nullptr;
     };
     if (env.kpt || env.hl || env.vw || env.xd >= 0 || env.wm) {
