@@ -1183,16 +1183,20 @@ extern "C" int amt_march_selectable(char *buf, int cap)
         }
     };
     for (int nk = 1; nk <= 400; ++nk)
-        for (int lay = 0; lay < 3; ++lay) {                          // aligned; even rows but unaligned; odd rows
-            AmtParams<double> pd = {};
-            AmtParams<float> pf = {};
-            pd.nk = pf.nk = nk;
-            pd.idim = pf.idim = lay == 2 ? 4099 : 4160;
-            if (lay >= 1) { pd.t_1 = reinterpret_cast<const double *>(8); pf.t_1 = reinterpret_cast<const float *>(4); }
-            AmtMarchShape q;
-            if (amt_march_pick(pd, q)) add("double", q);
-            if (amt_march_pick(pf, q)) add("float", q);
-        }
+        for (int lay = 0; lay < 2; ++lay)                            // even and odd row lengths
+            for (int win = 0; win < 2; ++win) {                      // a whole domain and a patch-sized launch
+                AmtParams<double> pd = {};
+                AmtParams<float> pf = {};
+                pd.nk = pf.nk = nk;
+                pd.idim = pf.idim = lay ? 4099 : 4160;
+                pd.i0 = pf.i0 = 32;
+                pd.i1 = pf.i1 = win ? 95 : 4095;
+                pd.j0 = pf.j0 = 1;
+                pd.j1 = pf.j1 = win ? 64 : 4096;
+                AmtMarchShape q;
+                if (amt_march_pick(pd, q)) add("double", q);
+                if (amt_march_pick(pf, q)) add("float", q);
+            }
     if (buf && cap > 0) {
         const int n = (int)s.size() < cap - 1 ? (int)s.size() : cap - 1;
         memcpy(buf, s.data(), n);
