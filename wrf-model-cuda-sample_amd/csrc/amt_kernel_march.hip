@@ -84,6 +84,12 @@ static int amt_env_int(const char *name, int dflt)
 #ifndef AMT_U_FROM_LANE
 #define AMT_U_FROM_LANE 0   /* DMA flavour: u, u_1 at column + 1 by a DPP lane shift instead of a second load */
 #endif
+#ifndef AMT_D2_REREAD
+#define AMT_D2_REREAD 0     /* muu, msfuy of a level re-read from LDS per level (0: held in registers across the levels) */
+#endif
+#ifndef AMT_CARRY_ROW2D
+#define AMT_CARRY_ROW2D 0   /* 1: msfty, mu_tend carried in registers from P1 to P3 instead of re-read from LDS */
+#endif
 #ifndef AMT_CHAIN
 #define AMT_CHAIN 10    /* LDS reads kept in flight by the sequential k chains */
 #endif
@@ -607,6 +613,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         unsigned o3 = vo + hoff;                       // per-lane byte offset of the current row
         for (int jj = ja; jj <= jb; ++jj, o3 += row3) {
             V hf[KPT], tw[KPT];
+            V msfty_c(T(1)), mu_tend_c(T(0));
             const int par = (jj - ja) & 1;
             const T *T1c = T1 + par * t1buf;                         // t_1 row j
             T *T1n = T1 + (par ^ 1) * t1buf;                         // t_1 row j+1 (DMA'd during the previous row / written now)
@@ -629,7 +636,14 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             }
             if ((AMT_U_FROM_LANE && DMA) ? inmem : act) {
                 const V msftx = amt_ldsv<T, VW>(D2 + 0 * TW + c);
-                const V mm = msftx * amt_ldsv<T, VW>(D2 + 1 * TW + c);
+                const V msfty_p1 = amt_ldsv<T, VW>(D2 + 1 * TW + c);
+                const V mm = msftx * msfty_p1;
+                if (AMT_CARRY_ROW2D) { msfty_c = msfty_p1; mu_tend_c = amt_ldsv<T, VW>(D2 + 6 * TW + c); }
+                V muu_i0, muu_ip0, msfuy_i0, msfuy_ip0;
+                if (!AMT_D2_REREAD) {
+                    muu_i0 = amt_ldsv<T, VW>(D2 + 2 * TW + c); muu_ip0 = amt_ldsv<T, VW>(D2 + 2 * TW + c + 1);
+                    msfuy_i0 = amt_ldsv<T, VW>(D2 + 3 * TW + c); msfuy_ip0 = amt_ldsv<T, VW>(D2 + 3 * TW + c + 1);
+                }
                 const V muv_p = amt_ldsv<T, VW>(D2 + 4 * TW + c), mvx_p = amt_ldsv<T, VW>(D2 + 5 * TW + c);
                 // Neighbour columns c-1 and c+VW are read unclamped: for the tile's first / last lane they
                 // fall into the adjacent LDS row (always inside the LDS image) and the halo value is
@@ -642,10 +656,13 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                     T un, u1n;                                               // u, u_1 at my last column + 1
                     // muu, msfuy at i and i+1: re-read per level through a laundered address (8 registers
                     // in fp64 that the level loop needs more than these four LDS reads cost)
-                    const T *d2m = D2 + 2 * TW + c;
-                    asm volatile("" : "+v"(d2m));
-                    const V muu_i = amt_ldsv<T, VW>(d2m), muu_ip = amt_ldsv<T, VW>(d2m + 1);
-                    const V msfuy_i = amt_ldsv<T, VW>(d2m + TW), msfuy_ip = amt_ldsv<T, VW>(d2m + TW + 1);
+                    V muu_i, muu_ip, msfuy_i, msfuy_ip;
+                    if (AMT_D2_REREAD) {
+                        const T *d2m = D2 + 2 * TW + c;
+                        asm volatile("" : "+v"(d2m));
+                        muu_i = amt_ldsv<T, VW>(d2m); muu_ip = amt_ldsv<T, VW>(d2m + 1);
+                        msfuy_i = amt_ldsv<T, VW>(d2m + TW); msfuy_ip = amt_ldsv<T, VW>(d2m + TW + 1);
+                    } else { muu_i = muu_i0; muu_ip = muu_ip0; msfuy_i = msfuy_i0; msfuy_ip = msfuy_ip0; }
                     if (DMA) { vn = amt_ldsv<T, VW>(VB + (kfw + m) * TC + lc); t1n = amt_ldsv<T, VW>(T1n + (kfw + m) * TC + lc); }
                     else {
                         vn = amt_ldv<T, VW>(v_b + js, om); t1n = amt_ldv<T, VW>(t1_b + js, om);
@@ -726,7 +743,9 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             amt_lds_barrier();                                       // 2: DM published (DMA keeps flying)
             V inc_last(T(0));                                       // my top level's increment (:161)
             if (act) {
-                const V dmdt = amt_ldsv<T, VW>(DM + c), mu_tend = amt_ldsv<T, VW>(DM + TC + c), msfty = amt_ldsv<T, VW>(DM + 2 * TC + c);
+                const V dmdt = amt_ldsv<T, VW>(DM + c);
+                const V mu_tend = AMT_CARRY_ROW2D ? mu_tend_c : amt_ldsv<T, VW>(DM + TC + c);
+                const V msfty = AMT_CARRY_ROW2D ? msfty_c : amt_ldsv<T, VW>(DM + 2 * TC + c);
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
                     const V inc = S1[4 * (kfw + m) + 4 * lh] * (dmdt + amt_ldsv<T, VW>(AB + (kfw + m) * TC + lc) + mu_tend) / msfty;   // :161
@@ -739,7 +758,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
 
             // ---------------- P3: vertical flux, theta ----------------
             if (act) {
-                const V msfty = amt_ldsv<T, VW>(DM + 2 * TC + c);
+                const V msfty = AMT_CARRY_ROW2D ? msfty_c : amt_ldsv<T, VW>(DM + 2 * TC + c);
                 V wwu = amt_ldsv<T, VW>(AB + kfw * TC + lc);           // ww of :161 at my first level
                 V wd_k = (kf == 0) ? V(T(0)) : (wwu - w1[0]) * tw[0];   // wdtn(i,1) = 0 (:220)
 #pragma unroll
