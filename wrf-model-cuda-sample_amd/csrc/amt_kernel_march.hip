@@ -14,7 +14,7 @@
 //          levels [h*KPT, (h+1)*KPT) of the wave's LW = HL*KPT levels, so a tile is TC = TI*VW
 //          columns wide.  HL = 2, 4 halve/quarter every [level][column] LDS buffer and the
 //          registers a level count needs: fp64 runs 61..120 levels with the 4 levels per lane
-//          (127 VGPRs, no scratch) that 60 levels use, 121..240 with HL = 4;
+//          that 60 levels use (no scratch), up to 264 with 6 levels per lane and HL = 4;
 //      KPT levels per lane.
 //    NC "cell" waves own LW consecutive levels each; one more "column" wave owns everything
 //    that is per column (i,j) rather than per cell: the two sequential k chains, the 2-D mass
@@ -46,8 +46,9 @@
 //    column wave runs its chains and the cell waves would otherwise only wait.  Barriers 2 and 3
 //    are LDS-only (inline asm): a __syncthreads() would drain the DMA (hipcc waits vmcnt(0) at a
 //    workgroup fence while an LDS-DMA is in flight); barrier 4 is a full one and is where the DMA
-//    must have landed.  Needs rows that are a multiple of 16 bytes and 16-byte aligned arrays;
-//    otherwise (DMA = false) the same rows go through registers inside P1.
+//    must have landed.  The DMA's global source needs no alignment (profiles/r02_lds_dma_alignment.md),
+//    so every layout takes this flavour; with DMA = false (AMT_MARCH_DMA=0, kept as a cross-check) the
+//    same rows go through registers inside P1.
 //
 // Reference semantics: module_small_step_em.f90:112-172 (mu, ww), :208-215 and
 // :217-250 (theta); the fusion of the three Fortran phases is legal because a
