@@ -309,7 +309,7 @@ int amt_calib_stream_copy(void *hip_stream, void *dst_device, const void *src_de
  *     register flavour, rows per workgroup, 16- or 11-wave build; 0 / -1 = leave it to the launcher) for every later
  *     call of the process -- a shape that cannot run the given level count makes the call fail
  *     (AMT_VARIANT_AUTO then falls back to the column kernel).  amt_march_last_kernel names the
- *     instantiation the calling thread's last plan chose; amt_march_selectable lists the ones the
+ *     kernel the calling thread's last launch plan chose (the column kernel included); amt_march_selectable lists the ones the
  *     launcher can choose unforced, one per line (returns the bytes needed).
  * ------------------------------------------------------------------------ */
 int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, int jrows, int max_waves);

@@ -8,6 +8,7 @@
 template <typename T> hipError_t amt_launch_column(hipStream_t, const AmtParams<T> &);
 template <typename T> hipError_t amt_launch_march(hipStream_t, const AmtParams<T> &);
 template <typename T> bool amt_march_supported(const AmtParams<T> &);
+void amt_march_note_kernel(const char *name);
 
 // ---------------------------------------------------------------------------
 // errors
@@ -132,6 +133,7 @@ static int amt_launch(hipStream_t stream, int variant, const AmtParams<T> &p)
             return amt_fail(AMT_ERR_PRECONDITION, "nk=%d: no kernel holds a column of more than %d levels in LDS",
                             p.nk, (int)(160 * 1024 / (64 * sizeof(T))));
         e = amt_launch_column<T>(stream, p);
+        amt_march_note_kernel(sizeof(T) == 8 ? "amt_column_kernel<double>" : "amt_column_kernel<float>");
     } else if (variant == AMT_VARIANT_MARCH) {
         if (!amt_march_supported(p))
             return amt_fail(AMT_ERR_INVALID_ARG, "AMT_VARIANT_MARCH does not support nk=%d", p.nk);

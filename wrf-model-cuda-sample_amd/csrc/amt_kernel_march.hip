@@ -14,7 +14,7 @@
 //          levels [h*KPT, (h+1)*KPT) of the wave's LW = HL*KPT levels, so a tile is TC = TI*VW
 //          columns wide.  HL = 2, 4 halve/quarter every [level][column] LDS buffer and the
 //          registers a level count needs: fp64 runs 61..120 levels with the 4 levels per lane
-//          that 60 levels use (no scratch), up to 264 with 6 levels per lane and HL = 4;
+//          that 60 levels use (no scratch), up to 240 (fp32: 264) with HL = 4, where LDS ends it;
 //      KPT levels per lane.
 //    NC "cell" waves own LW consecutive levels each; one more "column" wave owns everything
 //    that is per column (i,j) rather than per cell: the two sequential k chains, the 2-D mass
@@ -941,6 +941,7 @@ static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0};
 // The instantiation the last plan of the calling thread chose (diagnosis / tests): "" before any launch.
 static thread_local char g_march_last[160] = "";
 extern "C" const char *amt_march_last_kernel(void) { return g_march_last; }
+void amt_march_note_kernel(const char *name) { snprintf(g_march_last, sizeof g_march_last, "%s", name); }   // amt_api.hip: column kernel
 static int g_march_generation = 0;                 // bumped by amt_march_force_shape: cached plans are stale
 static std::once_flag g_march_env_once;
 static const AmtMarchEnv &amt_march_env()
