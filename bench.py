@@ -497,7 +497,8 @@ def run_rank(a):
                        "halo_overlap": (not a.no_overlap) if world > 1 else None,
                        "halo_transport": ("rccl" if a.backend == "nccl" else "gloo-host-staged (bring-up)") if world > 1 else None,
                        "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep(),
-                       "placement_probe_ms": probe_ms},
+                       "placement_probe_ms": probe_ms,
+                       "kernel": pkg.load_library().amt_march_last_kernel().decode()},
             "stepper": ("native amt_slab_* (C++ runtime, ncclSend/ncclRecv)" if native else
                         "torch.distributed P2P (patch.SlabStepper)") if world > 1 else "single launch per sweep",
             "ranks_seen": ranks_seen,
