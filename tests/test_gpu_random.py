@@ -15,8 +15,8 @@ N_CASES = int(os.environ.get("AMT_RANDOM_CASES", "40"))
 
 def random_case(pkg, rng):
     S = pkg.synth
-    ni = int(rng.choice([1, 2, 3, 31, 63, 64, 65, 127, 129, int(rng.integers(1, 300))]))
-    nk = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 40, 60, 61, int(rng.integers(1, 70))]))
+    ni = int(rng.choice([1, 2, 3, 31, 63, 64, 65, 127, 129, 257, int(rng.integers(1, 300)), int(rng.integers(1, 700))]))
+    nk = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 40, 60, 61, int(rng.integers(1, 70)), int(rng.integers(61, 300))]))
     nj = int(rng.choice([1, 2, 3, 5, 9, int(rng.integers(1, 40))]))
     ids, ide, jds, jde, kde = 1, ni + 1, 1, nj + 1, nk + 1
     ims = 1 - int(rng.integers(1, 70))
@@ -26,9 +26,9 @@ def random_case(pkg, rng):
     kms = int(rng.choice([1, 1, 0, -2]))
     kme = kde + int(rng.integers(0, 3))
     if rng.random() < 0.4:
-        # rows a multiple of 16 bytes: the LDS-DMA flavour of the march kernel, not the plain one,
-        # then runs these cases -- level counts that fill the cell waves and ragged ones
-        nk = int(rng.choice([1, 3, 4, 5, 7, 8, 12, 13, 16, 20, 23, 24, 27, 31, 35, 40, 45, 57, 60, 61, 70, 80]))
+        # level counts that fill the cell waves of some wave shape and ragged ones, on rows of a
+        # multiple of four elements (every other case has whatever row length falls out)
+        nk = int(rng.choice([1, 3, 4, 5, 7, 8, 12, 13, 16, 20, 23, 24, 27, 31, 35, 40, 45, 57, 60, 61, 70, 80, 88, 96, 120, 132, 176, 240]))
         kde, kme = nk + 1, nk + 1 + int(rng.integers(0, 3))
         ime += (-(ime - ims + 1)) % 4
     # tile: the whole domain, or a random sub-tile (as an OpenMP tile / slab would be)
@@ -49,19 +49,22 @@ def test_random_cases_match_oracle(pkg, oracle):
     rng = np.random.default_rng(20261002)
     S = pkg.synth
     ran = {"march": 0, "column": 0, "oneshot": 0}
+    L = pkg.load_library()
     for case in range(N_CASES):
         b, cfg, dtype, dims = random_case(pkg, rng)
         host = S.make_patch(b, cfg, dtype=dtype, seed=1000 + case, global_dims=dims)
         want = host.copy()
         oracle.advance_mu_t(*want.args())
         what = f"case {case}: bounds={b.as_tuple()} flags={cfg} dtype={np.dtype(dtype).name}"
+        # one case in five through the register flavour of the march kernel (AMT_MARCH_DMA=0's twin)
+        L.amt_march_force_shape(0, 0, 0, -1, 0 if case % 5 == 4 else 1, 0, 0)
         for variant, name in ((pkg.VARIANT_MARCH, "march"), (pkg.VARIANT_COLUMN, "column")):
             dev = host.to_device("cuda:0")
             try:
                 pkg.advance_mu_t(*dev.args(), variant=variant)
             except pkg.AmtError as e:
                 if variant == pkg.VARIANT_MARCH and e.status == 3:
-                    continue
+                    continue                    # no march shape for this level count (AUTO takes the column kernel)
                 raise AssertionError(f"{what}: {e}")
             torch.cuda.synchronize()
             got = dev.to_host()
@@ -74,4 +77,5 @@ def test_random_cases_match_oracle(pkg, oracle):
             for n in S.FIELD_NAMES:
                 assert bits_equal(one.arrays[n], want.arrays[n]), f"{what}: one-shot, {n} differs"
             ran["oneshot"] += 1
-    assert ran["march"] >= N_CASES * 0.9 and ran["column"] == N_CASES
+    L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
+    assert ran["march"] >= N_CASES * 0.8 and ran["column"] >= N_CASES * 0.95
