@@ -267,7 +267,12 @@ extern "C" int amt_slab_create(amt_slab **out, amt_domain *dom, int rank, int wo
     s->below = loopback ? rank : rank > 0 ? rank - 1 : -1;
     s->above = loopback ? rank : rank < world - 1 ? rank + 1 : -1;
     DeviceScope scope(dom->device);
-    hipError_t e = hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking);
+    // the communication stream outranks the domain's: the exchange and the two edge rows behind it are
+    // small and the sweep's join waits for them, so they must not queue behind the interior's
+    // remaining rounds of workgroups
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    hipError_t e = hipStreamCreateWithPriority(&s->comm_stream, hipStreamNonBlocking, prio_high);
     for (hipEvent_t *ev : {&s->inputs_final, &s->edges_done})
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&s->t0, &s->t1})

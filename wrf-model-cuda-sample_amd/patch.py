@@ -60,7 +60,9 @@ class SlabStepper:
         if self.on_gpu:
             import torch
             self.main_stream = torch.cuda.current_stream(any_arr.device)
-            self.comm_stream = torch.cuda.Stream(device=any_arr.device)
+            # high priority: the exchange and the edge rows are small and the sweep's join waits for them;
+            # they must not queue behind the interior's remaining rounds of workgroups
+            self.comm_stream = torch.cuda.Stream(device=any_arr.device, priority=-1)
         b = patch.bounds
         if world > 1 and (b.jme - b.jms + 1) != (b.jte - b.jts + 1) + 2:
             raise ValueError("a slab patch holds its rows plus exactly one halo row per side")
