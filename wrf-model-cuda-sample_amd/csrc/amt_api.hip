@@ -119,6 +119,7 @@ int amt_build_params(const AmtArgs<T> &a, AmtParams<T> &p, AmtWindow &w, bool *e
     p.j0 = w.j_start - a.jms; p.j1 = w.j_end - a.jms;
     p.k1 = 1 - a.kms;
     p.nk = w.k_end;            // levels 1..k_end (k_end may be 0)
+    p.edges = 0;
     return AMT_OK;
 }
 
@@ -147,6 +148,29 @@ static int amt_launch(hipStream_t stream, int variant, const AmtParams<T> &p)
     return AMT_OK;
 }
 
+// Only the first and the last row of the tile's window (amt_slab.hip: the two rows of a j-slab that
+// read a neighbour's halo), in one launch where the march kernel runs, in two otherwise.
+template <typename T>
+int amt_device_call_edges(void *hip_stream, int variant, const AmtArgs<T> &a)
+{
+    AmtParams<T> p;
+    AmtWindow w;
+    bool empty = false;
+    int rc = amt_build_params(a, p, w, &empty);
+    if (rc != AMT_OK || empty) return rc;
+    if (p.j1 == p.j0) return amt_launch<T>(static_cast<hipStream_t>(hip_stream), variant, p);
+    p.edges = 1;
+    if ((variant == AMT_VARIANT_AUTO || variant == AMT_VARIANT_MARCH) && amt_march_supported(p))
+        return amt_launch<T>(static_cast<hipStream_t>(hip_stream), AMT_VARIANT_MARCH, p);
+    p.edges = 0;
+    AmtParams<T> q = p;
+    q.j1 = p.j0;
+    rc = amt_launch<T>(static_cast<hipStream_t>(hip_stream), variant, q);
+    if (rc != AMT_OK) return rc;
+    q.j0 = q.j1 = p.j1;
+    return amt_launch<T>(static_cast<hipStream_t>(hip_stream), variant, q);
+}
+
 template <typename T>
 int amt_device_call(void *hip_stream, int variant, const AmtArgs<T> &a)
 {
@@ -162,6 +186,8 @@ template int amt_build_params<float>(const AmtArgs<float> &, AmtParams<float> &,
 template int amt_build_params<double>(const AmtArgs<double> &, AmtParams<double> &, AmtWindow &, bool *);
 template int amt_device_call<float>(void *, int, const AmtArgs<float> &);
 template int amt_device_call<double>(void *, int, const AmtArgs<double> &);
+template int amt_device_call_edges<float>(void *, int, const AmtArgs<float> &);
+template int amt_device_call_edges<double>(void *, int, const AmtArgs<double> &);
 
 extern "C" int amt_advance_mu_t_device_f32(void *hip_stream, int variant, AMT_SIG(float))
 {

@@ -47,10 +47,14 @@ struct AmtArgs {
 template <typename T> int amt_build_params(const AmtArgs<T> &a, AmtParams<T> &p, AmtWindow &w, bool *empty);
 // bounds check + kernel launch on a stream: the device-resident entry point (amt_api.hip)
 template <typename T> int amt_device_call(void *hip_stream, int variant, const AmtArgs<T> &a);
+// the same for the first and the last row of the window only (one launch where the march kernel runs)
+template <typename T> int amt_device_call_edges(void *hip_stream, int variant, const AmtArgs<T> &a);
 extern template int amt_build_params<float>(const AmtArgs<float> &, AmtParams<float> &, AmtWindow &, bool *);
 extern template int amt_build_params<double>(const AmtArgs<double> &, AmtParams<double> &, AmtWindow &, bool *);
 extern template int amt_device_call<float>(void *, int, const AmtArgs<float> &);
 extern template int amt_device_call<double>(void *, int, const AmtArgs<double> &);
+extern template int amt_device_call_edges<float>(void *, int, const AmtArgs<float> &);
+extern template int amt_device_call_edges<double>(void *, int, const AmtArgs<double> &);
 
 #define AMT_PACK_ARGS(T)                                                                        \
     AmtArgs<T> a;                                                                               \

@@ -99,6 +99,7 @@ struct AmtMarchGrid {
     int ntile_i;     // number of i tiles that hold window columns
     int tile_lo;     // first such tile
     int jrows;       // rows per workgroup
+    int jstep;       // rows from one j block's first row to the next one's (jrows; edge launches: j1 - j0)
     int njblk;       // number of j blocks
     int nwg;         // ntile_i * njblk
 };
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         S1[e] = src[p.k1 + (k < nk ? k : nk - 1)];
     }
 
-    const int ja   = p.j0 + jblk * g.jrows;
+    const int ja   = p.j0 + jblk * g.jstep;
     const int jb   = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
     const long idim = p.idim, js = p.jstride;
     const unsigned lev = (unsigned)idim * W;                  // byte step of one level
@@ -1053,7 +1054,7 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
         // (profiles/r02_small_domains.md: 64x40x64 11 -> 9 us, 128x60x128 fp64 30 -> 23 us), while in
         // a launch of several rounds it moves fewer bytes per second (512x60x512: 1.17x the time).
         {
-            const int nj = p.j1 - p.j0 + 1, cus = 256;
+            const int nj = p.edges ? 2 : p.j1 - p.j0 + 1, cus = 256;
             auto model = [&](const AmtMarchShape &q) {
                 const int tc = (64 / q.hl) * q.vw;
                 double c = 0;
@@ -1087,7 +1088,7 @@ template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
 // grid and rows per workgroup is made once).
 template <typename T> struct AmtMarchPlan {
     // key
-    int nk, idim, kdim, i0, i1, nj, dev, generation;
+    int nk, idim, kdim, i0, i1, nj, dev, generation, edges;
     bool dma_ok;
     // plan
     bool ok;
@@ -1133,7 +1134,13 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
     if (jrows > nj) jrows = nj;
     if (jrows > max_rows) jrows = (int)max_rows;
     g.jrows = jrows;
+    g.jstep = jrows;
     g.njblk = (nj + jrows - 1) / jrows;
+    if (p.edges) {                                   // rows j0 and j1 only: two one-row blocks
+        g.jrows = 1;
+        g.jstep = nj - 1;
+        g.njblk = 2;
+    }
     g.nwg = g.ntile_i * g.njblk;
     if (pl.lds > 64 * 1024 && !(pl.entry->lds_granted[pl.full] >> (pl.dev & 31) & 1u)) {
         // the attribute is per device and per kernel instantiation: allow all of the CU's LDS once
@@ -1162,13 +1169,14 @@ template <typename T> static const AmtMarchPlan<T> *amt_march_plan(const AmtPara
     for (int i = 0; i < used; ++i) {
         const AmtMarchPlan<T> &c = cache[i];
         if (c.nk == p.nk && c.idim == p.idim && c.kdim == p.kdim && c.i0 == p.i0 && c.i1 == p.i1 && c.nj == nj
-            && c.dev == dev && c.dma_ok == dma_ok && c.generation == g_march_generation)
+            && c.dev == dev && c.dma_ok == dma_ok && c.generation == g_march_generation && c.edges == p.edges)
             return c.ok ? &c : nullptr;
     }
     const int slot = used < NSLOT ? used++ : (next = (next + 1) % NSLOT);
     AmtMarchPlan<T> &c = cache[slot];
     c.nk = p.nk; c.idim = p.idim; c.kdim = p.kdim; c.i0 = p.i0; c.i1 = p.i1; c.nj = nj; c.dev = dev; c.dma_ok = dma_ok;
     c.generation = g_march_generation;
+    c.edges = p.edges;
     amt_march_make_plan(p, c);
     return c.ok ? &c : nullptr;
 }

@@ -21,6 +21,7 @@ struct AmtParams {
     int j0, j1;            // j_start - jms .. j_end - jms
     int k1;                // memory index of Fortran level k = 1   (1 - kms)
     int nk;                // k_end = kte - 1 : levels 1..nk are updated
+    int edges;             // 1: only rows j0 and j1 of the window (a j-slab's two boundary rows in ONE launch)
 };
 
 // Compute window, module_small_step_em.f90:91-106.

@@ -376,8 +376,16 @@ int amt_slab_step_t(amt_slab *s, int n_sweeps)
             rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi);
             if (rc) return rc;
         }
-        if (lo) { rc = amt_slab_tile<T>(s, edge_stream, jlo, jlo < jhi ? jlo : jhi); if (rc) return rc; }
-        if (hi && (jhi > jlo || !lo)) { rc = amt_slab_tile<T>(s, edge_stream, jhi, jhi); if (rc) return rc; }
+        if (lo && hi && jhi > jlo) {                                        // both boundary rows in one launch
+            AmtArgs<T> a;
+            amt_domain_args<T>(d, a);
+            a.jts = jlo; a.jte = jhi;
+            rc = amt_device_call_edges<T>(edge_stream, d->variant, a);
+            if (rc) return rc;
+        } else {
+            if (lo) { rc = amt_slab_tile<T>(s, edge_stream, jlo, jlo < jhi ? jlo : jhi); if (rc) return rc; }
+            if (hi && (jhi > jlo || !lo)) { rc = amt_slab_tile<T>(s, edge_stream, jhi, jhi); if (rc) return rc; }
+        }
         if (s->overlap) {
             AMT_HIP(hipEventRecord(s->edges_done, s->comm_stream));
             AMT_HIP(hipStreamWaitEvent(d->stream, s->edges_done, 0));
