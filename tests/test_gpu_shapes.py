@@ -18,6 +18,7 @@ SHAPES = [
     (F64, 1, 4, 2, 0, 1, 16), (F64, 1, 4, 2, 0, 0, 16),
     (F64, 1, 4, 2, 0, 1, 12), (F64, 1, 4, 2, 1, 1, 12), (F64, 1, 4, 2, 0, 0, 12),
     (F64, 1, 6, 2, 0, 1, 12), (F64, 1, 6, 2, 0, 0, 12),
+    (F64, 1, 3, 1, 0, 1, 16), (F64, 1, 3, 2, 0, 1, 16),
     (F64, 1, 2, 2, 0, 1, 16), (F64, 1, 2, 2, 3, 1, 16),
     (F64, 1, 4, 4, 0, 1, 16), (F64, 1, 4, 4, 0, 0, 16), (F64, 1, 4, 4, 0, 1, 12), (F64, 1, 4, 4, 0, 0, 12),
     (F64, 1, 6, 4, 0, 1, 12), (F64, 1, 6, 4, 0, 0, 12),
@@ -31,6 +32,7 @@ SHAPES = [
     (F32, 2, 4, 2, 0, 1, 16), (F32, 2, 4, 2, 0, 0, 16),
     (F32, 2, 4, 2, 0, 1, 12), (F32, 2, 4, 2, 1, 1, 12), (F32, 2, 4, 2, 0, 0, 12),
     (F32, 2, 6, 2, 0, 1, 12), (F32, 2, 6, 2, 0, 0, 12),
+    (F32, 2, 3, 1, 0, 1, 16), (F32, 2, 3, 2, 0, 1, 16),
     (F32, 2, 4, 4, 0, 1, 16), (F32, 2, 4, 4, 0, 0, 16), (F32, 2, 4, 4, 0, 1, 12), (F32, 2, 4, 4, 0, 0, 12),
     (F32, 2, 6, 4, 0, 1, 12), (F32, 2, 6, 4, 0, 0, 12),
 ]

@@ -42,9 +42,11 @@ def test_selectable_instantiations_have_no_scratch(pkg):
 def test_every_level_count_up_to_128_has_a_march_kernel(pkg):
     """NK <= 128 never falls to the column kernel in either precision on the resident layout."""
     names = "\n".join(_selectable(pkg))
-    for must in ("amt_march_kernel<double, 1, 4, 1, 0, true, true, 16>",      # <= 60 levels
-                 "amt_march_kernel<double, 1, 4, 2, 0, true, true, 12>",      # <= 88
+    for must in ("amt_march_kernel<double, 1, 3, 1, 0, true, true, 16>",      # <= 45 levels
+                 "amt_march_kernel<double, 1, 4, 1, 0, true, true, 16>",      # <= 60
+                 "amt_march_kernel<double, 1, 3, 2, 0, true, true, 16>",      # <= 90
+                 "amt_march_kernel<double, 1, 4, 2, 0, false, true, 16>",     # <= 120 (the general build)
                  "amt_march_kernel<double, 1, 6, 2, 0, true, true, 12>",      # <= 132
                  "amt_march_kernel<float, 2, 4, 1, 0, true, true, 16>",
-                 "amt_march_kernel<float, 2, 4, 2, 0, true, true, 12>"):
+                 "amt_march_kernel<float, 2, 3, 2, 0, true, true, 16>"):
         assert must in names, must

@@ -506,24 +506,46 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         constexpr int EPL = 16 / (int)sizeof(T);           // elements per lane of one DMA instruction
         constexpr int LPL = TC / EPL;                      // lanes per level row
         constexpr int LPI = 64 / LPL;                      // levels per DMA instruction
-        static_assert(!DMA || (LW % LPI == 0 && LPL >= 1 && LPL <= 64), "a cell wave must own whole DMA instructions");
+        static_assert(!DMA || (LPL >= 1 && LPL <= 64), "a level row of the tile is at most one DMA instruction");
         // copies the wave's LW levels of j row (ja + rows) of `src` (uniform base at row ja) to lds
         auto dma_rows = [&](int ln, const T *src, int rows, T *lds) {
             const int dl = ln / LPL;                                         // level within the instruction
             const unsigned dch = (unsigned)(ln % LPL) * 16u;                 // my 16-byte chunk of the row
             const bool dok = tile * TC + (ln % LPL) * EPL < p.idim;          // chunk lies inside the memory row
+            if constexpr (LW % LPI == 0) {
+                // a wave fetches the levels it computes
 #pragma unroll
-            for (int q = 0; q < LW / LPI; ++q) {
-                const char *ub = reinterpret_cast<const char *>(src) + (FULL ? (size_t)(q * LPI) * lev : (size_t)0);
-                unsigned ro = (unsigned)dl * lev + dch + (unsigned)rows * row3;   // the row advance rides in the lane offset
-                if (!FULL) {                                                     // virtual levels read the last real one
-                    const int l = q * LPI + dl;
-                    ro = (unsigned)(l < nrw ? l : nrw - 1) * lev + dch + (unsigned)rows * row3;
+                for (int q = 0; q < LW / LPI; ++q) {
+                    const char *ub = reinterpret_cast<const char *>(src) + (FULL ? (size_t)(q * LPI) * lev : (size_t)0);
+                    unsigned ro = (unsigned)dl * lev + dch + (unsigned)rows * row3;   // the row advance rides in the lane offset
+                    if (!FULL) {                                                     // virtual levels read the last real one
+                        const int l = q * LPI + dl;
+                        ro = (unsigned)(l < nrw ? l : nrw - 1) * lev + dch + (unsigned)rows * row3;
+                    }
+                    if (dok)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
+                                                         (__attribute__((address_space(3))) void *)(lds + (size_t)(kfw + q * LPI) * TC),
+                                                         16, 0, AMT_NT_DMA);
                 }
-                if (dok)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
-                                                     (__attribute__((address_space(3))) void *)(lds + (size_t)(kfw + q * LPI) * TC),
-                                                     16, 0, AMT_NT_DMA);
+            } else {
+                // levels per wave are not whole DMA instructions (3 or 5 levels per lane): the instructions of
+                // the tile's nkr level rows are dealt round-robin to the cell waves, whatever levels they compute
+                const int ninst = (nkr + LPI - 1) / LPI;
+#pragma unroll
+                for (int n = 0; n < (LW + LPI - 1) / LPI; ++n) {
+                    const int q = w + n * nc;                                    // wave-uniform
+                    if (q < ninst) {
+                        const int g0 = q * LPI;                                  // first level row of the instruction
+                        const int g0c = g0 < nk - 1 ? g0 : nk - 1;               // source level rows are clamped to the real ones
+                        const char *ub = reinterpret_cast<const char *>(src) + ((long)g0c - (long)kfw) * (long)lev;
+                        const int dmax = nk - 1 - g0c;
+                        const unsigned ro = (unsigned)(dl < dmax ? dl : dmax) * lev + dch + (unsigned)rows * row3;
+                        if (dok && g0 + dl < nkr)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + ro),
+                                                             (__attribute__((address_space(3))) void *)(lds + (size_t)g0 * TC),
+                                                             16, 0, AMT_NT_DMA);
+                    }
+                }
             }
         };
         // i halo of a t_1 row: per level the elements left of column 0 and right of column TC-1, one
@@ -832,22 +854,22 @@ static bool amt_march_shape_valid(int wbytes, const AmtMarchShape &s)
 {
     if (s.vw != 1 && s.vw != 2) return false;
     if (s.hl != 1 && s.hl != 2 && s.hl != 4) return false;
-    if (s.kpt != 2 && s.kpt != 4 && s.kpt != 6 && s.kpt != 8) return false;
+    if (s.kpt < 2 || s.kpt > 8 || s.kpt == 7) return false;
     if (s.wm != 16 && s.wm != 12) return false;
     if (s.xd < 0 || s.xd > 3 || (s.xd && !s.dma)) return false;
     if (s.dma) {
         const int tc = (64 / s.hl) * s.vw, epl = 16 / wbytes, lpl = tc / epl;
-        if (lpl < 1 || lpl > 64 || (s.kpt * s.hl) % (64 / lpl) != 0) return false;   // whole DMA instructions per wave
+        if (lpl < 1 || lpl > 64) return false;                         // a level row is at most one DMA instruction
     }
     return true;
 }
 
 // The FULL = true build of a shape skips the clamping of virtual levels; where that build needs
-// scratch and the general one does not (fp64 with level groups at 16 waves: 12 B/lane against 0),
+// scratch and the general one does not (fp64, 4 levels per lane with level groups at 16 waves: 12 B/lane against 0),
 // the general build also runs the level counts that fill the waves.
 static bool amt_march_full_build_ok(int wbytes, const AmtMarchShape &s)
 {
-    return !(wbytes == 8 && s.hl > 1 && s.wm == 16);
+    return !(wbytes == 8 && s.hl > 1 && s.wm == 16 && s.kpt >= 4);
 }
 
 static bool amt_march_shape_feasible(int wbytes, const AmtMarchShape &s, int nk)
@@ -865,6 +887,7 @@ static bool amt_march_shape_feasible(int wbytes, const AmtMarchShape &s, int nk)
     X(double, 1, 4, 2, 0, true, 16) X(double, 1, 4, 2, 0, false, 16)                             \
     X(double, 1, 4, 2, 0, true, 12) X(double, 1, 4, 2, 1, true, 12) X(double, 1, 4, 2, 0, false, 12)    \
     X(double, 1, 6, 2, 0, true, 12) X(double, 1, 6, 2, 0, false, 12)                             \
+    X(double, 1, 3, 1, 0, true, 16) X(double, 1, 3, 2, 0, true, 16)                              \
     X(double, 1, 2, 2, 0, true, 16) X(double, 1, 2, 2, 3, true, 16)                              \
     X(double, 1, 4, 4, 0, true, 16) X(double, 1, 4, 4, 0, false, 16)                             \
     X(double, 1, 4, 4, 0, true, 12) X(double, 1, 4, 4, 0, false, 12)                             \
@@ -881,6 +904,7 @@ static bool amt_march_shape_feasible(int wbytes, const AmtMarchShape &s, int nk)
     X(float, 2, 4, 2, 0, true, 16) X(float, 2, 4, 2, 0, false, 16)                               \
     X(float, 2, 4, 2, 0, true, 12) X(float, 2, 4, 2, 1, true, 12) X(float, 2, 4, 2, 0, false, 12)       \
     X(float, 2, 6, 2, 0, true, 12) X(float, 2, 6, 2, 0, false, 12)                               \
+    X(float, 2, 3, 1, 0, true, 16) X(float, 2, 3, 2, 0, true, 16)                                \
     X(float, 2, 4, 4, 0, true, 16) X(float, 2, 4, 4, 0, false, 16)                               \
     X(float, 2, 4, 4, 0, true, 12) X(float, 2, 4, 4, 0, false, 12)                               \
     X(float, 2, 6, 4, 0, true, 12) X(float, 2, 6, 4, 0, false, 12)
@@ -1004,14 +1028,18 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
     const AmtMarchEnv &env = amt_march_env();
     const bool dma_ok = env.dma != 0 && amt_march_dma_layout_ok(p);
     const int wb = (int)sizeof(T);
-    // only instantiations without scratch are listed (tests/test_kernel_resources.py checks the build)
+    // only instantiations without scratch are listed (tests/test_kernel_resources.py checks the build).
+    // Order: as many cell waves as the 16-wave budget gives (memory-level parallelism; profiles/r02_shapes.md:
+    // 3 levels per lane beat 4 by 1-2.4 % wherever they add waves), then the 12-wave builds.
     static const AmtMarchShape pref64[] = {
-        {1, 2, 1, 3, true, 16}, {1, 4, 1, 0, true, 16}, {1, 4, 2, 0, true, 12}, {1, 4, 2, 0, true, 16}, {1, 6, 2, 0, true, 12},
+        {1, 2, 1, 3, true, 16}, {1, 3, 1, 0, true, 16}, {1, 4, 1, 0, true, 16}, {1, 3, 2, 0, true, 16}, {1, 4, 2, 0, true, 12},
+        {1, 4, 2, 0, true, 16}, {1, 6, 2, 0, true, 12},
         {1, 4, 4, 0, true, 12}, {1, 4, 4, 0, true, 16}, {1, 6, 4, 0, true, 12},
         {1, 2, 1, 0, false, 16}, {1, 4, 1, 0, false, 16}, {1, 4, 2, 0, false, 12}, {1, 4, 4, 0, false, 12}};
     static const AmtMarchShape pref32[] = {
         {2, 2, 1, 3, true, 16},   // <= 30 levels: 15 cell waves of 2 levels (4096x30x4096: 4.12 against 4.62 ms)
-        {2, 4, 1, 0, true, 16}, {2, 4, 2, 0, true, 12}, {2, 4, 2, 0, true, 16}, {2, 6, 2, 0, true, 12},
+        {2, 3, 1, 0, true, 16}, {2, 4, 1, 0, true, 16}, {2, 3, 2, 0, true, 16}, {2, 4, 2, 0, true, 12}, {2, 4, 2, 0, true, 16},
+        {2, 6, 2, 0, true, 12},
         {2, 4, 4, 0, true, 12}, {2, 4, 4, 0, true, 16}, {2, 6, 4, 0, true, 12},
         {2, 4, 1, 0, false, 16}, {2, 4, 2, 0, false, 12}, {2, 4, 2, 0, false, 16},
         {2, 4, 4, 0, false, 12}, {2, 4, 4, 0, false, 16},
