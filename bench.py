@@ -376,6 +376,7 @@ def run_rank(a):
     poison_halos()
     torch.cuda.synchronize()
     ranks_seen = 1
+    native_error, p2p_group = None, None
     if native:
         # phase 1, no collective: every rank must be able to open RCCL; agree before anyone blocks
         # in ncclCommInitRank waiting for a rank that cannot come
@@ -391,11 +392,29 @@ def run_rank(a):
         if flag.item() < 0.5:
             raise SystemExit(f"rank {rank}: RCCL is not usable for the native stepper: {err or 'another rank failed'}")
         dist.broadcast_object_list(uid, src=0)
-        stepper = pkg.patch.NativeSlabStepper(dev, rank, world, uid[0], stream=main_stream,
-                                              overlap=not a.no_overlap, variant=a.variant)
-        ranks_seen = stepper.comm_info()[1]
-    else:
-        stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap,
+        # phase 2, collective (ncclCommInitRank): if it fails, it fails on every rank (they all agree below);
+        # the run then goes on with the torch.distributed stepper and SAYS so in its line -- a measurement
+        # with the cross-check stepper beats none
+        stepper = None
+        try:
+            stepper = pkg.patch.NativeSlabStepper(dev, rank, world, uid[0], stream=main_stream,
+                                                  overlap=not a.no_overlap, variant=a.variant)
+        except pkg.AmtError as e:
+            native_error = str(e)
+        flag = torch.tensor([0.0 if stepper is None else 1.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 0.5:
+            if stepper is not None:
+                stepper.close()
+            native, stepper = False, None
+            native_error = native_error or "the native stepper could not be created on another rank"
+            print(f"bench.py rank {rank}: native stepper unavailable ({native_error}); falling back to --stepper torch",
+                  file=sys.stderr, flush=True)
+            p2p_group = dist.new_group(backend="nccl")
+        else:
+            ranks_seen = stepper.comm_info()[1]
+    if not native:
+        stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap, group=p2p_group,
                                         variant=a.variant, stage_through_host=(a.backend == "gloo"))
         if world > 1:
             ranks_seen = dist.get_world_size()
@@ -502,6 +521,7 @@ def run_rank(a):
             "stepper": ("native amt_slab_* (C++ runtime, ncclSend/ncclRecv)" if native else
                         "torch.distributed P2P (patch.SlabStepper)") if world > 1 else "single launch per sweep",
             "ranks_seen": ranks_seen,
+            "native_stepper_error": native_error,
             "rank_ms_per_step_min_max": [round(x, 4) for x in rank_ms],
             "launched_by": "bench.py self-launch" if os.environ.get("AMT_BENCH_SELF_LAUNCHED") else
                            ("external launcher" if world > 1 else "direct"),
