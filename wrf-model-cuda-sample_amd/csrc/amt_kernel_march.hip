@@ -82,14 +82,18 @@ static int amt_env_int(const char *name, int dflt)
 #ifndef AMT_NT_DMA
 #define AMT_NT_DMA 0    /* cache-policy bits of the bulk LDS-DMA loads (2 = nt) */
 #endif
+// Measured alternatives kept as build switches (profiles/r02_shapes.md; A/B by build with profiles/ab_libs.py):
 #ifndef AMT_U_FROM_LANE
-#define AMT_U_FROM_LANE 0   /* DMA flavour: u, u_1 at column + 1 by a DPP lane shift instead of a second load */
+#define AMT_U_FROM_LANE 0   /* DMA flavour: u, u_1 at column + 1 by a DPP lane shift instead of a second load: two global
+                               loads per level fewer, but ~30 more VGPRs in hipcc's schedule and 15 % slower */
 #endif
 #ifndef AMT_D2_REREAD
-#define AMT_D2_REREAD 0     /* muu, msfuy of a level re-read from LDS per level (0: held in registers across the levels) */
+#define AMT_D2_REREAD 0     /* 1: muu, msfuy of a level re-read from LDS per level instead of held across the levels:
+                               saves 8 VGPRs in fp64, costs 1.7 % at 4096x60x4096 */
 #endif
 #ifndef AMT_CARRY_ROW2D
-#define AMT_CARRY_ROW2D 0   /* 1: msfty, mu_tend carried in registers from P1 to P3 instead of re-read from LDS */
+#define AMT_CARRY_ROW2D 0   /* 1: msfty, mu_tend carried in registers from P1 to P3 instead of re-read from LDS: +4 VGPRs
+                               in fp64, no gain */
 #endif
 #ifndef AMT_CHAIN
 #define AMT_CHAIN 10    /* LDS reads kept in flight by the sequential k chains */
