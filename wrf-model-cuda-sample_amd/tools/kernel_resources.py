@@ -55,16 +55,29 @@ def main():
         sys.exit(1 if bad else 0)
 
 
+def selectable_names():
+    """The instantiations amt_launch_march can pick without an AMT_MARCH_* override, from the library
+    itself (amt_march_selectable: the launcher's own preference lists run over level counts, layouts and
+    launch sizes -- pure host logic, no GPU needed)."""
+    import ctypes
+    lib = CSRC.parent / "libamt_advance_mu_t.so"
+    L = ctypes.CDLL(str(lib))
+    L.amt_march_selectable.restype = ctypes.c_int
+    L.amt_march_selectable.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    n = L.amt_march_selectable(None, 0)
+    buf = ctypes.create_string_buffer(n)
+    L.amt_march_selectable(buf, n)
+    return set(buf.value.decode().split("\n")) - {""}
+
+
+_names = None
+
+
 def selectable(r) -> bool:
-    """Can amt_launch_march pick this instantiation without an AMT_MARCH_* override?  Mirrors the
-    preference lists of amt_march_kpt / amt_march_launch_dma in csrc/amt_kernel_march.hip; the
-    launcher's own table (amt_march_selectable, exported for tests) is the authority -- this is the
-    offline twin used at build time, and tests/test_kernel_resources.py checks that they agree."""
-    sel = CSRC / "build" / "march_selectable.json"
-    if sel.exists():
-        table = json.loads(sel.read_text())
-        return f"{r['kernel']}<{r['targs']}>" in table
-    return True
+    global _names
+    if _names is None:
+        _names = selectable_names()
+    return f"{r['kernel']}<{r['targs']}>" in _names
 
 
 if __name__ == "__main__":
