@@ -49,18 +49,22 @@ def parse():
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 column, 2 march")
     ap.add_argument("--seed", type=int, default=12345)
-    ap.add_argument("--probe-placements", type=int, default=1,
-                    help="allocate the state this many times, time 2 sweeps on each copy and keep the fastest "
-                         "(the sweep time depends on where the ten 8 GB arrays land in HBM: +-4 %% between "
-                         "allocations, stable within one); 1 = take the first allocation as it comes")
+    ap.add_argument("--probe-placements", type=int, default=3,
+                    help="allocate the state this many times (one after the other), time 2 sweeps on each and keep "
+                         "the fastest: the sweep time depends on which physical pages the driver hands out (up to 5 %% "
+                         "between allocations, stable within one); every timing is reported; 1 = take the first "
+                         "allocation as it comes; skipped when two copies do not fit")
     ap.add_argument("--idim-extra", type=int, default=0, help="extra elements of i padding at the end of each row")
     ap.add_argument("--align-elems", type=int, default=32,
                     help="i padding of the resident layout: i = its sits this many elements into a row")
     ap.add_argument("--no-overlap", action="store_true", help="exchange halos before computing (no 2nd stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-box-probe", action="store_true",
+                    help="skip the in-process streaming ceilings (roofline.box_*) and the clock / power snapshot")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=64, help="j rows of the CPU-baseline sample")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-rows", type=int, default=256,
+                    help="j rows of the CPU-baseline slab sample (at least one per granted core; capped by free host memory)")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the whole CPU-baseline leg, fill time included")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU projection: do the per-sweep work of ONE rank of an N-slab run (interior + "
                          "edge launches, second stream, halo rows copied device-to-device from local buffers); "
@@ -72,9 +76,91 @@ def parse():
     ap.add_argument("--stepper", choices=("native", "torch"), default="native",
                     help="N > 1: native = amt_slab_* (ncclSend/ncclRecv inside the C++ runtime, what a Fortran "
                          "host calls); torch = torch.distributed P2P ops around the same launches")
-    ap.add_argument("--launch-timeout", type=float, default=1800.0,
+    ap.add_argument("--launch-timeout", type=float, default=600.0,
                     help="self-launch (N > 1 without a launcher): give up and end every rank after this many seconds")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="N > 1 with fewer GPUs than ranks and the RCCL transport: map ranks onto the visible devices "
+                         "anyway.  RCCL refuses two ranks on one device -- this drives the failure path (diagnosis, clean "
+                         "non-zero exit of every rank) on a one-GPU box; never a measurement")
+    ap.add_argument("--comm-timeout", type=float, default=120.0,
+                    help="N > 1: most seconds a rank waits in the communicator set-up (ncclCommInitRank) and in the "
+                         "first halo exchange before it ends itself with a diagnosis")
     return ap.parse_args()
+
+
+def gpu_state_smi():
+    """Clocks, power and power cap as rocm-smi reports them (a child process; called BEFORE this process
+    touches the GPU, so it is the idle state of the box -- the clocks under load come from sysfs, below)."""
+    import subprocess
+    out = {}
+    for flag, key in (("--showclocks", "clocks"), ("--showpower", "power"), ("--showmaxpower", "power_cap"),
+                      ("--showperflevel", "perf_level"), ("--showtemp", "temperature")):
+        try:
+            r = subprocess.run(["rocm-smi", flag, "--json"], capture_output=True, text=True, timeout=20)
+            d = json.loads(r.stdout)
+            out[key] = d.get("card0", d)
+        except Exception as e:  # noqa: BLE001
+            out[key] = f"unavailable ({type(e).__name__})"
+    return out
+
+
+def gpu_state_sysfs(index=0):
+    """sclk / mclk / fclk levels (the starred one is current) and socket power from sysfs: cheap enough to
+    read while kernels are in flight."""
+    out = {}
+    cards = sorted(Path("/sys/class/drm").glob("card[0-9]*/device/pp_dpm_sclk"))
+    if not cards:
+        return None
+    dev = cards[min(index, len(cards) - 1)].parent
+    for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+        try:
+            cur = [ln.strip() for ln in (dev / name).read_text().splitlines() if "*" in ln]
+            out[name[7:]] = cur[0] if cur else None
+        except OSError:
+            pass
+    for hw in dev.glob("hwmon/hwmon*/power1_average"):
+        try:
+            out["power_W"] = int(hw.read_text()) / 1e6
+            out["power_cap_W"] = int((hw.parent / "power1_cap").read_text()) / 1e6
+        except (OSError, ValueError):
+            pass
+    return out or None
+
+
+def box_ceilings(pkg, stream, device, nbytes=4 << 30):
+    """The box's own streaming rates, in this process, on `stream`: a tuned 16-byte-per-lane copy
+    (nbytes read + nbytes written) and a read-only sweep (amt_calib_stream_rate).  GB/s, best of three
+    rounds of four launches each; plus the sysfs clocks sampled while the copies are in flight."""
+    import ctypes
+    import torch
+    L = pkg.load_library()
+    src = torch.empty(nbytes // 8, dtype=torch.float64, device=device).fill_(1.0)
+    dst = torch.empty_like(src)
+    h = ctypes.c_void_p(stream.cuda_stream)
+    out = {}
+    under_load = None
+    for mode, key in ((0, "box_copy_GBps"), (1, "box_read_GBps")):
+        def launch():
+            pkg.lib.check(L.amt_calib_stream_rate(h, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()),
+                                                  ctypes.c_size_t(nbytes), mode))
+        launch()
+        torch.cuda.synchronize()
+        best = float("inf")
+        for rnd in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(4 if rnd else 40):          # the first round is long enough to read the clocks under load
+                launch()
+            e1.record(stream)
+            if rnd == 0 and mode == 0:
+                time.sleep(0.02)
+                under_load = gpu_state_sysfs(device.index or 0)
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / (4 if rnd else 40))
+        out[key] = round((2 if mode == 0 else 1) * nbytes / best / 1e6, 1)
+    del src, dst
+    torch.cuda.empty_cache()
+    return out, under_load
 
 
 def algorithmic_bytes(ni, nk, nj, itemsize):
@@ -138,65 +224,107 @@ def host_cores():
     return n, note
 
 
-def cpu_baseline(pkg, oracle, dims, dtype, seed, rows, seconds):
-    """SURVEY.md section 8(d) / BASELINE.md section 4: the CPU restatement of the Fortran (oracle/, C,
-    `gcc -O3 -march=native -ffp-contract=off`: the checker's bits), timed at 64x40x64, 512x60x512 and on
-    a j-slab of the bench domain, on one thread and j-tiled over all host cores with OpenMP (the scheme
-    of advance_mu_t_driver.f90:175-209), every tile's pages first touched by the thread that computes it;
-    and the reference Fortran itself (oracle/_ref, one thread, INCLUDING its five whole-array debug
-    dumps per call, module_small_step_em.f90:175-189, written to /dev/null).  `value` is the slab run
-    on all cores.  Bounded: `seconds` caps every entry."""
+def mem_available_bytes():
+    try:
+        for ln in Path("/proc/meminfo").read_text().splitlines():
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) * 1024
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
+def cpu_baseline(dims, dtype_name, seed, rows, seconds):
+    """SURVEY.md section 8(d) / BASELINE.md section 4, timed on this box's host cores in the same run:
+
+      fortran           the build's own Fortran-90 CPU path (oracle/fortran/advance_mu_t_cpu.f90: same
+                        48-argument signature, fused single pass over j, i-blocked, no dumps, OpenMP over
+                        j-tiles as sketched in advance_mu_t_driver.f90:175-209; amdflang -O3 -march=native
+                        -ffp-contract=off; bit-equal to tests/golden/) -- `value` is this one on all granted cores
+      port_c            the C restatement the parity tests use as the checker (gcc -O3 -march=native)
+      reference_fortran_compute_only
+                        the REFERENCE routine itself compiled -O3 with its five debug dumps
+                        (module_small_step_em.f90:175-189) cut out; one thread, as the reference runs it
+      reference_fortran_incl_dumps   the reference as shipped (dumps to /dev/null): an I/O number, for context
+
+    at 64x40x64, 512x60x512 and a j-slab of the bench domain sized by --cpu-rows and the host's free memory,
+    on one thread and on all the cores the process is granted (count stated).  Every entry is its own child
+    process (oracle/cpu_bench.py; no GPU is touched there) under a timeout: one that fails costs its entry,
+    never the bench line.  Bounded: `seconds` is the budget of the whole leg, fill time included."""
+    import subprocess
     ni, nk, nj = dims
     cores, quota_note = host_cores()
-    slab_rows = max(1, min(nj, max(rows, 1024)))
-    budget = max(0.5, seconds / 6.0)                              # per entry
-    matrix = []
+    itemsize = 8 if dtype_name == "f64" else 4
+    avail = mem_available_bytes()
+    row_bytes = 10.5 * (ni + 2) * (nk + 1) * itemsize                  # ten 3-D arrays + the 2-D ones
+    slab_rows = max(cores, min(nj, rows))
+    if avail:
+        slab_rows = max(1, min(slab_rows, int(0.3 * avail / row_bytes)))
+    t_leg = time.perf_counter()
+    matrix, errors = [], []
+    worker = str(ROOT / "oracle" / "cpu_bench.py")
 
-    def run(shape, threads, what):
-        n_i, n_k, n_j = shape
-        threads = max(1, min(threads, n_j))
-        cells = n_i * n_k * n_j
-        est = cells / (150e6 * (threads ** 0.8))                  # rough seconds per sweep
-        reps = int(max(3, min(30, budget / max(est, 1e-4))))
-        ms, fill = oracle.bench(dtype, n_i, n_k, n_j, threads, reps, gj0=max(0, (nj - n_j) // 2), gnj=max(nj, n_j), seed=seed)
-        med = float(np.median(ms[1:] if len(ms) > 1 else ms))
-        rec = {"impl": "port_c_O3", "size": f"{n_i}x{n_k}x{n_j}" + (f" ({what})" if what else ""), "threads": threads,
-               "Mcells_s": round(cells / med / 1e3, 2), "ms_per_sweep": round(med, 4), "sweeps": len(ms)}
+    def run(impl, shape, threads, what="", gj0=0, gnj=0, share=1.0):
+        left = seconds - (time.perf_counter() - t_leg)
+        if left <= 0.5:
+            errors.append(f"{impl} {shape} x{threads}: skipped, the leg's {seconds:.0f} s budget is spent")
+            return None
+        budget = max(0.3, min(left, seconds * share / 12.0))
+        cmd = [sys.executable, worker, "--impl", impl, "--dtype", dtype_name, "--size", *map(str, shape),
+               "--threads", str(threads), "--seconds", f"{budget:.2f}", "--seed", str(seed), "--gj0", str(gj0), "--gnj", str(gnj)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(20.0, 4 * left),
+                               env=dict(os.environ, ORACLE_BENCH_FILL_THREADS=str(cores)))
+            if r.returncode != 0:
+                raise RuntimeError(f"exit {r.returncode}: {r.stderr.strip()[-300:]}")
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001  (an OOM kill, a timeout, a compiler that is not there ...)
+            errors.append(f"{impl} {'x'.join(map(str, shape))} x{threads}: {type(e).__name__}: {str(e)[-300:]}")
+            return None
+        name = {"c": "port_c", "fortran": "fortran", "reference_nodump": "reference_fortran_compute_only",
+                "reference": "reference_fortran_incl_dumps"}[impl]
+        rec = {"impl": name, "size": rec["size"] + (f" ({what})" if what else ""), "threads": rec["threads"],
+               "Mcells_s": rec["Mcells_s"], "ms_per_sweep": rec["ms_per_sweep"], "sweeps": rec["sweeps"], "fill_s": rec["fill_s"]}
         matrix.append(rec)
         return rec
 
-    run((64, 40, 64), 1, "")
-    run((64, 40, 64), cores, "")
-    run((512, 60, 512), 1, "")
-    run((512, 60, 512), cores, "")
-    slab = run((ni, nk, slab_rows), cores, "j-slab of the bench domain, first touch by the computing thread")
-    out = {"value": slab["Mcells_s"], "unit": "Mcells/s", "cores": slab["threads"], "kind": "port",
-           "sample": f"{ni}x{nk}x{slab_rows} j-slab of the same synthetic domain, median of {slab['sweeps'] - 1} sweeps, "
-                     f"C restatement of the Fortran, gcc -O3 -march=native -ffp-contract=off, OpenMP j-tiles "
-                     f"({slab['threads']} threads), pages first touched by their tile's thread",
-           "ms_per_sweep_sample": slab["ms_per_sweep"],
-           "one_thread_Mcells_s": matrix[2]["Mcells_s"],
-           "host": quota_note,
+    slab_shape = (ni, nk, slab_rows)
+    gj0 = max(0, (nj - slab_rows) // 2)
+    slab_what = "j-slab of the bench domain, first touch by the computing thread"
+    slab = run("fortran", slab_shape, cores, slab_what, gj0, nj, share=3.0)        # the reported value first
+    one = run("fortran", (512, 60, 512), 1)
+    run("fortran", (512, 60, 512), cores)
+    run("fortran", (64, 40, 64), 1)
+    run("fortran", (64, 40, 64), cores)
+    have_ref = (ROOT / "oracle" / "_ref" / f"libref_nodump_{dtype_name}.so").exists()
+    if have_ref:
+        run("reference_nodump", (512, 60, 512), 1)
+        run("reference_nodump", (64, 40, 64), 1)
+    run("c", slab_shape, cores, slab_what, gj0, nj, share=2.0)
+    run("c", (512, 60, 512), 1)
+    run("c", (512, 60, 512), cores)
+    if (ROOT / "oracle" / "_ref" / f"libref_amt_{dtype_name}.so").exists():
+        run("reference", (64, 40, 64), 1)
+    out = {"value": slab["Mcells_s"] if slab else None, "unit": "Mcells/s", "cores": slab["threads"] if slab else cores,
+           "kind": "port",
+           "impl": "fortran: oracle/fortran/advance_mu_t_cpu.f90, the build's own Fortran-90 restatement (fused, i-blocked, "
+                   "OpenMP j-tiles; amdflang -O3 -march=native -ffp-contract=off; bit-equal to the reference's outputs in tests/golden/)",
+           "sample": f"{ni}x{nk}x{slab_rows} j-slab (rows {gj0 + 1}..{gj0 + slab_rows}) of the same synthetic domain, median sweep, "
+                     f"{slab['threads'] if slab else cores} OpenMP j-tiles, pages first touched by their tile's thread",
+           "ms_per_sweep_sample": slab["ms_per_sweep"] if slab else None,
+           "one_thread_Mcells_s": one["Mcells_s"] if one else None,
+           "host": quota_note + (f", MemAvailable {avail / 2**30:.0f} GiB" if avail else ""),
+           "leg_seconds": round(time.perf_counter() - t_leg, 1),
            "matrix": matrix}
-    # the reference Fortran itself (built from the reference's sources where they lie; oracle/_ref)
-    if oracle.have_ref(np.dtype(dtype).itemsize):
-        S = pkg.synth
-        for shape in ((64, 40, 64), (128, 60, 128)):
-            b = S.domain_bounds(*shape)
-            p2 = S.make_patch(b, pkg.GridConfig(), dtype=dtype, seed=seed, global_dims=shape)
-            t2 = []
-            t_end = time.perf_counter() + budget
-            while len(t2) < 2 or (time.perf_counter() < t_end and len(t2) < 10):
-                t0 = time.perf_counter()
-                oracle.ref_advance_mu_t(*p2.args())
-                t2.append(time.perf_counter() - t0)
-            matrix.append({"impl": "reference_fortran_incl_dumps", "size": "x".join(map(str, shape)), "threads": 1,
-                           "Mcells_s": round(np.prod(shape) / float(np.median(t2)) / 1e6, 2),
-                           "ms_per_sweep": round(float(np.median(t2)) * 1e3, 3), "sweeps": len(t2)})
-        out["reference_fortran_incl_dumps_one_thread_Mcells_s"] = matrix[-1]["Mcells_s"]
-        out["reference_note"] = ("amdflang -O2 -ffp-contract=off; every call writes five whole arrays (muave, mu, mudf, "
-                                 "muts, ww) as unformatted big-endian streams (here to /dev/null): that, not the "
-                                 "arithmetic, is most of its time")
+    ref = [m for m in matrix if m["impl"] == "reference_fortran_compute_only"]
+    if ref:
+        out["reference_fortran_compute_only_one_thread_Mcells_s"] = ref[0]["Mcells_s"]
+        out["reference_note"] = ("reference_fortran_compute_only = /root/reference/module_small_step_em.f90 with lines 175-189 "
+                                 "(five whole-array debug dumps, 99.6 % of its as-shipped wall time) cut out at build time, "
+                                 "amdflang -O3 -ffp-contract=off, one thread (oracle/Makefile, target ref); "
+                                 "reference_fortran_incl_dumps is the routine as shipped, dumps to /dev/null: an I/O number")
+    if errors:
+        out["errors"] = errors
     return out
 
 
@@ -251,53 +379,135 @@ def self_launch(a):
     """`python bench.py --gpus N` with no launcher around it: this process (which never touches a
     GPU) starts N rank processes of this same script with RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT set, lets rank 0 print the JSON line on the inherited stdout, and
-    returns the worst exit code.  A rank that dies takes the others down with it (by pid)."""
+    returns the worst exit code.  Every rank runs in its own session (process group): a rank that
+    dies takes the others down after 10 s, and so do a timeout, SIGTERM / SIGINT to this process and
+    any exception here -- by process group id, nothing is ever matched by name.  The ranks' stderr
+    comes through tagged `[rank r]`; RCCL runs with NCCL_DEBUG=WARN unless the caller set it."""
+    import signal
     import socket
     import subprocess
+    import threading
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     nonce = f"{os.getpid()}-{time.time_ns()}"
-    procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
-                   LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   AMT_RENDEZVOUS_NONCE=nonce, AMT_BENCH_SELF_LAUNCHED="1")
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    deadline = time.monotonic() + a.launch_timeout
+    procs, pumps = [], []
+
+    def teardown(sig=signal.SIGKILL):
+        for p in procs:                          # the exact process groups started below, nothing else
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, _frame):
+        print(f"bench.py: signal {signum}: ending the {len(procs)} rank processes", file=sys.stderr, flush=True)
+        teardown()
+        raise SystemExit(128 + signum)
+
+    def pump(stream, tag):
+        for line in iter(stream.readline, b""):
+            sys.stderr.write(f"[rank {tag}] " + line.decode(errors="replace"))
+            sys.stderr.flush()
+        stream.close()
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    failed_at = None
-    while any(p.poll() is None for p in procs):
-        codes = [p.poll() for p in procs]
-        bad = [c for c in codes if c not in (None, 0)]
-        if bad and failed_at is None:
-            failed_at = time.monotonic()
-            rc = bad[0]
-        timed_out = time.monotonic() > deadline
-        if timed_out or (failed_at is not None and time.monotonic() - failed_at > 10.0):
-            for p in procs:                      # the exact processes started above, nothing else
-                if p.poll() is None:
-                    p.kill()
-            if timed_out:
-                print(f"bench.py: self-launch timed out after {a.launch_timeout:.0f} s", file=sys.stderr)
-                rc = rc or 124
-            break
-        time.sleep(0.05)
-    for p in procs:
-        p.wait()
-        if p.returncode and not rc:
-            rc = p.returncode
+    try:
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                       LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       AMT_RENDEZVOUS_NONCE=nonce, AMT_BENCH_SELF_LAUNCHED="1")
+            env.setdefault("NCCL_DEBUG", "WARN")
+            p = subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                 stdout=None if r == 0 else subprocess.PIPE, stderr=subprocess.PIPE,
+                                 start_new_session=True)
+            procs.append(p)
+            for stream in ((p.stderr,) if r == 0 else (p.stderr, p.stdout)):
+                t = threading.Thread(target=pump, args=(stream, r), daemon=True)
+                t.start()
+                pumps.append(t)
+        deadline = time.monotonic() + a.launch_timeout
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad and failed_at is None:
+                failed_at = time.monotonic()
+                rc = bad[0][1]
+                print(f"bench.py: rank {bad[0][0]} exited with code {bad[0][1]}; the others get 10 s", file=sys.stderr, flush=True)
+            timed_out = time.monotonic() > deadline
+            if timed_out or (failed_at is not None and time.monotonic() - failed_at > 10.0):
+                if timed_out:
+                    alive = [r for r, p in enumerate(procs) if p.poll() is None]
+                    print(f"bench.py: self-launch timed out after {a.launch_timeout:.0f} s; ranks still running: {alive}",
+                          file=sys.stderr, flush=True)
+                    rc = rc or 124
+                teardown()
+                break
+            time.sleep(0.05)
+        for p in procs:
+            try:
+                p.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                pass
+            if p.returncode and not rc:
+                rc = p.returncode
+    finally:
+        teardown()
+        for t in pumps:
+            t.join(timeout=2)
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
 
 
+class StepTimeout(RuntimeError):
+    pass
+
+
+def watchdog(fn, seconds, what):
+    """Run fn() on a helper thread and wait at most `seconds`: the calls that can block for ever inside RCCL
+    (ncclCommInitRank while a peer never arrives, the first send/recv of a connection) must not take the
+    rank -- and with it the whole launch -- past the driver's own time limit without a diagnosis."""
+    import threading
+    box = {}
+
+    def body():
+        try:
+            box["value"] = fn()
+        except BaseException as e:  # noqa: BLE001
+            box["error"] = e
+    th = threading.Thread(target=body, daemon=True, name=f"amt-{what}")
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        raise StepTimeout(f"{what}: no return after {seconds:.0f} s")
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
+def die(rank, code, msg):
+    """End THIS rank now with a message (the self-launcher, or torchrun, then ends its peers): a rank that
+    cannot go on must not sit in a collective its peers will never reach."""
+    print(f"bench.py rank {rank}: FATAL: {msg}", file=sys.stderr, flush=True)
+    os._exit(code)                               # not SystemExit: a helper thread may still be blocked inside RCCL
+
+
 def run_rank(a):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("AMT_BENCH_TEST_HANG"):      # tests/test_bench_contract.py: a rank that never comes back
+        print(f"rank {rank} pid {os.getpid()} hanging for the teardown test", file=sys.stderr, flush=True)
+        time.sleep(float(os.environ["AMT_BENCH_TEST_HANG"]))
+        raise SystemExit(0)
+    smi_idle = gpu_state_smi() if rank == 0 and not a.no_box_probe else None     # before anything touches the GPU
     import torch
     import torch.distributed as dist
     import __graft_entry__ as g
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     a.gpus = world
     if not torch.cuda.is_available():
@@ -306,6 +516,8 @@ def run_rank(a):
     if a.backend == "gloo":
         a.stepper = "torch"                        # bring-up mode: host-staged rows, ranks may share a GPU
         local_rank = local_rank % ndev
+    elif world > 1 and a.share_gpu:
+        local_rank = local_rank % ndev             # failure-path bring-up: RCCL will refuse two ranks on one device
     elif world > 1 and local_rank >= ndev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible (RCCL needs one "
                          "GPU per rank; --backend gloo shares a GPU for bring-up)")
@@ -314,12 +526,14 @@ def run_rank(a):
     native = world > 1 and a.stepper == "native"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=max(60.0, 2 * a.comm_timeout + 60.0))     # never the 30-minute default
         if a.backend == "nccl" and not native:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=pg_timeout)
         else:
             # native stepper: RCCL lives inside the C++ runtime; torch.distributed (gloo, host side)
             # only carries the communicator id, the barriers and the max over ranks of the timings
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
 
     pkg = g.load_package()
     S = pkg.synth
@@ -336,24 +550,34 @@ def run_rank(a):
     torch.cuda.set_stream(main_stream)
     dev = S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device=device)
     probe_ms = None
-    if a.probe_placements > 1:
-        # placement probe: same data, different allocations; keep the copy whose sweep is fastest
-        probe_ms, best = [], None
-        cands = [dev] + [S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device=device)
-                         for _ in range(a.probe_placements - 1)]
-        for cnd in cands:
+    state_bytes = sum(t.numel() * t.element_size() for t in dev.arrays.values())
+    if a.probe_placements > 1 and torch.cuda.mem_get_info(device)[0] > 1.05 * state_bytes + (9 << 30):
+        # Placement probe.  Where the driver puts the arrays' pages moves this sweep by up to 5 % (same
+        # virtual addresses, fresh physical pages: 15.4 .. 16.2 ms in one process, profiles/r03_placement.md);
+        # nothing below 2 MiB of the addresses matters, so it cannot be steered -- only sampled.  Same data,
+        # K allocations one after the other (at most two resident at a time), two timed sweeps on each, the
+        # fastest is kept and refilled; every timing goes into the line (config.placement_probe_ms).
+        def timed2(cnd):
             call = pkg.bind_device_call(*cnd.args(), variant=a.variant)
             call()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); call(); call(); e1.record()
             torch.cuda.synchronize()
-            probe_ms.append(round(e0.elapsed_time(e1) / 2, 3))
-        k = int(np.argmin(probe_ms))
-        keep = cands[k]
-        del cands, cnd, call
+            return e0.elapsed_time(e1) / 2
+        probe_ms = [round(timed2(dev), 3)]
+        best_ms = probe_ms[0]
+        for k in range(1, a.probe_placements):
+            spacer = torch.empty((k * 1237 + 311) << 20, dtype=torch.uint8, device=device)    # shifts what follows
+            cnd = S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device=device)
+            del spacer
+            ms = timed2(cnd)
+            probe_ms.append(round(ms, 3))
+            if ms < best_ms:
+                best_ms, dev = ms, cnd
+            del cnd
+            torch.cuda.empty_cache()                   # the loser's pages go back to the driver
         # the probe advanced the state: refill the kept copy in place from the generator
-        dev = keep
         L = pkg.load_library()
         import ctypes as _ct
         for name in S.FIELD_NAMES:
@@ -362,7 +586,12 @@ def run_rank(a):
             pkg.lib.check(L.amt_synth_fill_device(_ct.c_void_p(torch.cuda.current_stream().cuda_stream), S.FIELD_ID[name],
                                                   t.element_size(), _ct.c_void_p(t.data_ptr()), _ct.c_uint64(a.seed), *fa))
         torch.cuda.synchronize()
-        torch.cuda.empty_cache()
+    ceilings, clocks_under_load = None, None
+    if not a.no_box_probe and torch.cuda.mem_get_info(device)[0] > (9 << 30):
+        try:
+            ceilings, clocks_under_load = box_ceilings(pkg, main_stream, device)
+        except Exception as e:  # noqa: BLE001
+            ceilings = {"error": f"{type(e).__name__}: {e}"}
 
     def poison_halos():
         # only a working exchange gives the right answer
@@ -392,25 +621,44 @@ def run_rank(a):
         if flag.item() < 0.5:
             raise SystemExit(f"rank {rank}: RCCL is not usable for the native stepper: {err or 'another rank failed'}")
         dist.broadcast_object_list(uid, src=0)
-        # phase 2, collective (ncclCommInitRank): if it fails, it fails on every rank (they all agree below);
-        # the run then goes on with the torch.distributed stepper and SAYS so in its line -- a measurement
-        # with the cross-check stepper beats none
-        stepper = None
+        # phase 2, collective (ncclCommInitRank).  It runs on a helper thread under a watchdog, so that every
+        # rank reaches the agreement below within --comm-timeout whatever its peers do.  Outcomes, worst over ranks:
+        #   every rank has its communicator            -> the native stepper is timed;
+        #   clean failure (an error code) somewhere   -> all ranks go on with the torch.distributed stepper and
+        #                                                 the line SAYS so (a cross-check measurement beats none);
+        #   a rank still blocked inside RCCL           -> every rank ends itself, non-zero, with what it knows.
+        def where():
+            return (f"rank {rank}/{world} device {local_rank} MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} "
+                    f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG', 'unset')} HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}")
+        stepper, state = None, 2
         try:
-            stepper = pkg.patch.NativeSlabStepper(dev, rank, world, uid[0], stream=main_stream,
-                                                  overlap=not a.no_overlap, variant=a.variant)
+            stepper = watchdog(lambda: pkg.patch.NativeSlabStepper(dev, rank, world, uid[0], stream=main_stream,
+                                                                   overlap=not a.no_overlap, variant=a.variant),
+                               a.comm_timeout, "amt_slab_create (ncclCommInitRank)")
+        except StepTimeout as e:
+            native_error, state = f"{e}; {where()}", 0
         except pkg.AmtError as e:
-            native_error = str(e)
-        flag = torch.tensor([0.0 if stepper is None else 1.0], dtype=torch.float64)
+            native_error, state = f"{e}; {where()}", 1
+        flag = torch.tensor([float(state)], dtype=torch.float64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if flag.item() < 0.5:
+            die(rank, 5, native_error or "another rank is blocked in ncclCommInitRank; ending this rank too")
+        if flag.item() < 1.5:
             if stepper is not None:
-                stepper.close()
+                try:
+                    watchdog(stepper.close, 20.0, "amt_slab_destroy")
+                except Exception:  # noqa: BLE001
+                    pass
             native, stepper = False, None
             native_error = native_error or "the native stepper could not be created on another rank"
             print(f"bench.py rank {rank}: native stepper unavailable ({native_error}); falling back to --stepper torch",
                   file=sys.stderr, flush=True)
-            p2p_group = dist.new_group(backend="nccl")
+            import datetime
+            try:
+                p2p_group = watchdog(lambda: dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=a.comm_timeout)),
+                                     a.comm_timeout + 10, "torch.distributed nccl group for the fallback stepper")
+            except Exception as e:  # noqa: BLE001
+                die(rank, 5, f"no RCCL path at all: native: {native_error}; torch.distributed: {type(e).__name__}: {e}")
         else:
             ranks_seen = stepper.comm_info()[1]
     if not native:
@@ -423,8 +671,14 @@ def run_rank(a):
         # establish the RCCL point-to-point connections outside any timed or verified step (the
         # first send/recv between two ranks builds their channels, which takes seconds);
         # the inputs are static, so an extra exchange changes nothing
-        stepper.exchange_halos()
-        torch.cuda.synchronize()
+        def first_exchange():
+            stepper.exchange_halos()
+            torch.cuda.synchronize()
+        try:
+            watchdog(first_exchange, a.comm_timeout, "first halo exchange (RCCL connection set-up)")
+        except Exception as e:  # noqa: BLE001  (a rank that cannot exchange must not leave its peers waiting for ever)
+            die(rank, 6, f"{type(e).__name__}: {e}; rank {rank}/{world} device {local_rank}, stepper "
+                         f"{'native' if native else 'torch'}, neighbours {[r for r in (rank - 1, rank + 1) if 0 <= r < world]}")
         poison_halos()                             # the verification must see the in-step exchange
         torch.cuda.synchronize()
         dist.barrier()
@@ -485,12 +739,18 @@ def run_rank(a):
         abytes = algorithmic_bytes(a.ni, a.nk, a.nj, itemsize)
         achieved = abytes / world / ev_per_step_s / 1e9              # GB/s per GPU (slowest rank)
         traffic, traffic_source = None, None
+        # reads / writes of one launch for the box's mixed streaming ceiling: the PMC record when there is one,
+        # the algorithmic split (8 reads + 3 writes per cell, 10 + 4 per column) otherwise
+        rd_bytes = itemsize * a.ni * a.nj * (8 * a.nk + 10) / world
+        wr_bytes = itemsize * a.ni * a.nj * (3 * a.nk + 4) / world
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():
             try:
                 rec = json.loads(tf.read_text()).get(f"{a.ni}x{a.nk}x{a.nj}_{a.dtype}_n{world}")
                 if rec:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    if rec.get("read_bytes") and rec.get("write_bytes"):
+                        rd_bytes, wr_bytes = rec["read_bytes"], rec["write_bytes"]
                     traffic_source = (f"profiles/hbm_traffic.json <- {rec.get('source', '?')} (rocprofv3 --pmc passes of "
                                       f"this command, collected by profiles/collect.sh; a recorded measurement, "
                                       f"not re-measured in this run)")
@@ -533,6 +793,29 @@ def run_rank(a):
                          "aggregate_GBps": round(abytes / ev_per_step_s / 1e9, 1)},
             "verified_vs_oracle": verified,
         }
+        if ceilings and "box_copy_GBps" in ceilings:
+            # Attribution of the sweep time to the box or to the kernel.  A copy moves one byte out per byte in;
+            # this sweep reads 2.7x what it writes, and reads stream faster than writes, so the box's ceiling for
+            # THIS mix is  reads / read_rate + writes / write_rate,  with the write rate inferred from the copy.
+            cp, rdr = ceilings["box_copy_GBps"], ceilings["box_read_GBps"]
+            inv_w = 2.0 / cp - 1.0 / rdr                                   # seconds per GB written
+            mixed_ms = (rd_bytes / rdr + wr_bytes * max(inv_w, 1.0 / rdr)) / 1e6
+            moved = (traffic / world if traffic and world > 1 else traffic) or (rd_bytes + wr_bytes)
+            out["roofline"].update({
+                "box_copy_GBps": cp, "box_read_GBps": rdr,
+                "box_write_GBps_inferred": round(1.0 / max(inv_w, 1.0 / rdr), 1),
+                "box_mixed_ceiling_ms": round(mixed_ms, 4),
+                "frac_of_box_copy": round(moved / ev_per_step_s / 1e9 / cp, 4),
+                "frac_of_box_mixed": round(mixed_ms / (ev_per_step_s * 1e3), 4),
+                "box_note": "box_* are this box's own streaming rates measured in this process just before the timed sweeps "
+                            "(amt_calib_stream_rate, 2 x 4 GiB, 16 B per lane; the guide's figure for a good box is ~6.3 TB/s): "
+                            "frac_of_box_copy = HBM bytes moved per launch / launch time / box_copy; frac_of_box_mixed = the time the "
+                            "box needs to stream this launch's reads and writes at its own rates / launch time.  A low `frac` with "
+                            "frac_of_box_mixed near 1 is a slow box, not a slow kernel."})
+        elif ceilings:
+            out["roofline"]["box_error"] = ceilings.get("error")
+        if smi_idle is not None or clocks_under_load is not None:
+            out["gpu_state"] = {"idle_before_run": smi_idle, "under_load_sysfs": clocks_under_load}
         if why:
             out["verify_message"] = why
         if fp32_err is not None:
@@ -540,8 +823,10 @@ def run_rank(a):
                                           "stated_tolerance": 2e-5,
                                           "within_tolerance": bool(fp32_err <= 2e-5)}
         if world == 1 and not a.no_cpu_baseline:
-            oracle = oracle or g.load_oracle()
-            out["cpu_baseline"] = cpu_baseline(pkg, oracle, dims, dtype, a.seed, a.cpu_rows, a.cpu_seconds)
+            try:
+                out["cpu_baseline"] = cpu_baseline(dims, a.dtype, a.seed, a.cpu_rows, a.cpu_seconds)
+            except Exception as e:  # noqa: BLE001  (the ancillary leg never costs the GPU line)
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
 
     if world > 1:

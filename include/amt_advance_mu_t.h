@@ -302,6 +302,13 @@ int amt_slab_max(amt_slab *slab, double *x);
  * ------------------------------------------------------------------------ */
 int amt_calib_stream_copy(void *hip_stream, void *dst_device, const void *src_device,
                           size_t nbytes, int bytes_per_lane);
+/* The box's own streaming ceilings, for attributing a measured sweep time to the machine or to the
+ * kernel (bench.py: roofline.box_copy_GBps / box_read_GBps, measured in the same process): mode 0 copies
+ * nbytes from src to dst (nbytes read + nbytes written), mode 1 only reads src (dst: 8 bytes that are never
+ * written for finite data).  16 bytes per lane, tuned for gfx950; nbytes a multiple of 16.  Asynchronous:
+ * time it with events on hip_stream. */
+int amt_calib_stream_rate(void *hip_stream, void *dst_device, const void *src_device,
+                          size_t nbytes, int mode);
 
 /* ------------------------------------------------------------------------
  * (7) Tuning and test hooks of AMT_VARIANT_MARCH: force the wave shape
@@ -313,6 +320,10 @@ int amt_calib_stream_copy(void *hip_stream, void *dst_device, const void *src_de
  *     launcher can choose unforced, one per line (returns the bytes needed).
  * ------------------------------------------------------------------------ */
 int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, int jrows, int max_waves);
+/* The block schedule of launches that run for several rounds of workgroups: 1 (default) = the launcher's rule
+ * (one segment of rows per XCD, blocks of decreasing length so that the launch's tail is short; DESIGN.md
+ * section 4), 0 = uniform blocks only, n > 1 = tapered with blocks of at most n rows.  Also AMT_MARCH_TAPER. */
+int amt_march_set_taper(int taper);
 const char *amt_march_last_kernel(void);
 int amt_march_selectable(char *buf, int cap);
 

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""oracle/cpu_bench.py -- TEST INFRASTRUCTURE ONLY: one CPU-baseline measurement per process.
+
+bench.py's cpu_baseline leg starts this script once per matrix entry (a child process that never
+touches a GPU): a crash, an out-of-memory kill or a timeout of one entry costs that entry, not the
+bench line, and the C port (gcc, libgomp) and the Fortran CPU path (amdflang, LLVM OpenMP) never
+share a process.
+
+  --impl c                 oracle/oracle_bench.c: the C restatement, -O3 -march=native, OpenMP j-tiles,
+                           pages first touched by the thread that computes them
+  --impl fortran           oracle/fortran/advance_mu_t_cpu.f90: the build's own Fortran-90 CPU path
+                           (fused, i-blocked, OpenMP j-tiles), same harness on the LLVM OpenMP runtime
+  --impl reference_nodump  the REFERENCE Fortran compiled -O3 with its five debug dumps cut out
+                           (oracle/_ref/libref_nodump_*.so; timing only), one thread
+  --impl reference         the reference as shipped, dumps included (to /dev/null), one thread
+
+Prints one JSON record: impl, size, threads, Mcells_s, ms_per_sweep (median), sweeps, fill_s.
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--impl", choices=("c", "fortran", "reference_nodump", "reference"), required=True)
+    ap.add_argument("--dtype", choices=("f32", "f64"), default="f64")
+    ap.add_argument("--size", type=int, nargs=3, required=True, metavar=("NI", "NK", "NJ"))
+    ap.add_argument("--threads", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=2.0, help="time budget of the timed sweeps")
+    ap.add_argument("--gj0", type=int, default=0, help="global row of the slab's first memory row")
+    ap.add_argument("--gnj", type=int, default=0, help="rows of the whole domain (0: the slab is the domain)")
+    ap.add_argument("--seed", type=int, default=12345)
+    a = ap.parse_args()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("amt_oracle", HERE / "oracle.py")
+    O = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(O)
+    dtype = np.float64 if a.dtype == "f64" else np.float32
+    ni, nk, nj = a.size
+    cells = ni * nk * nj
+    threads = max(1, min(a.threads, nj))
+    fill = None
+    if a.impl in ("c", "fortran"):
+        # a short probe sets the repetition count for the budget
+        probe, _ = O.bench(dtype, ni, nk, min(nj, max(threads, 8)), threads, 2, gj0=a.gj0, gnj=a.gnj or nj, seed=a.seed, impl=a.impl)
+        est = max(min(probe), 1e-3) * 1e-3 * nj / min(nj, max(threads, 8))
+        reps = int(max(3, min(30, a.seconds / est)))
+        ms, fill = O.bench(dtype, ni, nk, nj, threads, reps, gj0=a.gj0, gnj=a.gnj or nj, seed=a.seed, impl=a.impl)
+        ms = ms[1:] if len(ms) > 3 else ms
+        sweeps = reps
+    else:
+        import __graft_entry__ as g
+        pkg = g.load_package()          # host-side generator only (amt_synth_fill_host); no device is touched
+        S = pkg.synth
+        b = S.domain_bounds(ni, nk, nj)
+        p = S.make_patch(b, pkg.GridConfig(), dtype=dtype, seed=a.seed, global_dims=(ni, nk, nj))
+        fn = O.ref_nodump_advance_mu_t if a.impl == "reference_nodump" else O.ref_advance_mu_t
+        threads = 1
+        ms = []
+        t_end = time.perf_counter() + a.seconds
+        while len(ms) < 3 or (time.perf_counter() < t_end and len(ms) < 30):
+            t0 = time.perf_counter()
+            fn(*p.args())
+            ms.append((time.perf_counter() - t0) * 1e3)
+        sweeps = len(ms)
+    med = float(np.median(ms))
+    print(json.dumps({"impl": a.impl, "size": f"{ni}x{nk}x{nj}", "dtype": a.dtype, "threads": threads,
+                      "Mcells_s": round(cells / med / 1e3, 2), "ms_per_sweep": round(med, 4), "sweeps": sweeps,
+                      "fill_s": None if fill is None else round(fill, 3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,8 @@ ctypes front end of the CPU checker for the advance_mu_t path:
   the Fortran routine, numpy arrays updated in place.
 * ``advance_mu_t_omp(...)``  -- the same, j-tiled over host threads (the scheme
   sketched in advance_mu_t_driver.f90:175-209); timed by bench.py's cpu_baseline leg.
+* ``fortran_advance_mu_t(...)`` -- the build's own Fortran-90 CPU path (oracle/fortran/
+  advance_mu_t_cpu.f90: fused, i-blocked, OpenMP j-tiles), the CPU baseline bench.py reports.
 * ``ref_advance_mu_t(...)``  -- the REFERENCE Fortran itself (oracle/_ref/, built by
   ``make -C oracle ref`` from the sources under /root/reference; exists only where
   that build has run).  Used to pin the restatement and to generate tests/golden/.
@@ -27,6 +29,9 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "liboracle_amt.so"
 REF_PATHS = {4: HERE / "_ref" / "libref_amt_f32.so", 8: HERE / "_ref" / "libref_amt_f64.so"}
+# timing only: the reference with its five debug dumps cut out (oracle/Makefile, target ref)
+REF_NODUMP_PATHS = {4: HERE / "_ref" / "libref_nodump_f32.so", 8: HERE / "_ref" / "libref_nodump_f64.so"}
+FORTRAN_CPU_PATHS = {4: HERE / "libamt_cpu_fortran_f32.so", 8: HERE / "libamt_cpu_fortran_f64.so"}
 
 # the five dump files the reference writes into the cwd on every call
 # (module_small_step_em.f90:175-189)
@@ -52,7 +57,7 @@ def build(ref: bool | None = None) -> None:
 
 
 _lib = None
-_ref_libs: dict[int, ctypes.CDLL] = {}
+_ref_libs: dict = {}
 
 
 def _sig(real, extra_int=0):
@@ -75,7 +80,64 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def _native_dir() -> Path:
+    """oracle/_native/<hash of this CPU's model and flags>/: builds made -march=native on THIS machine."""
+    import hashlib
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln for ln in f if ln.startswith(("model name", "flags"))), "")
+            model += "".join(ln for ln in f if ln.startswith("flags"))[:4000]
+    except OSError:
+        pass
+    return HERE / "_native" / hashlib.sha1(model.encode()).hexdigest()[:12]
+
+
+_fortran_libs: dict = {}
+
+
+def fortran_lib(itemsize: int, native: bool = False) -> ctypes.CDLL:
+    """The Fortran CPU path.  native=False: the in-tree build (-O3 -ffp-contract=off, what the tests
+    hold against tests/golden/); native=True: the same source built -march=native on this machine
+    (what bench.py times; same bits, tests/test_fortran_cpu.py)."""
+    key = (itemsize, native)
+    if key not in _fortran_libs:
+        if native:
+            out = _native_dir()
+            path = out / FORTRAN_CPU_PATHS[itemsize].name
+            src = HERE / "fortran" / "advance_mu_t_cpu.f90"
+            if not path.exists() or path.stat().st_mtime < src.stat().st_mtime:
+                subprocess.run(["make", "-C", str(HERE), f"FCPU_OUT={out}", "FNATIVE=-march=native", "fortran_cpu"],
+                               check=True, capture_output=True)
+        else:
+            path = FORTRAN_CPU_PATHS[itemsize]
+            if not path.exists():
+                subprocess.run(["make", "-C", str(HERE), "fortran_cpu"], check=True, capture_output=True)
+        L = ctypes.CDLL(str(path))
+        real = ctypes.c_float if itemsize == 4 else ctypes.c_double
+        L.amt_cpu_fortran.argtypes, L.amt_cpu_fortran.restype = _sig(real, 1), ctypes.c_int
+        _fortran_libs[key] = L
+    return _fortran_libs[key]
+
+
 _bench_lib = None
+_bench_llvm_lib = None
+
+
+def bench_llvm_lib() -> ctypes.CDLL:
+    """oracle_bench.c on the LLVM OpenMP runtime (the Fortran CPU path's), built on this machine."""
+    global _bench_llvm_lib
+    if _bench_llvm_lib is None:
+        out = _native_dir() / "liboracle_bench_llvm.so"
+        if not out.exists() or out.stat().st_mtime < (HERE / "oracle_bench.c").stat().st_mtime:
+            subprocess.run(["make", "-C", str(HERE), f"BENCH_LLVM_OUT={out}", str(out)], check=True, capture_output=True)
+        L = ctypes.CDLL(str(out))
+        L.oracle_bench_fn.restype = ctypes.c_int
+        L.oracle_bench_fn.argtypes = [ctypes.c_int] * 4 + [ctypes.c_long, ctypes.c_long, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                                           ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
+        _bench_llvm_lib = L
+    return _bench_llvm_lib
 
 
 def bench_lib() -> ctypes.CDLL:
@@ -83,15 +145,7 @@ def bench_lib() -> ctypes.CDLL:
     machine (the in-tree liboracle_bench.so may come from another CPU)."""
     global _bench_lib
     if _bench_lib is None:
-        import hashlib
-        model = ""
-        try:
-            with open("/proc/cpuinfo") as f:
-                model = next((ln for ln in f if ln.startswith(("model name", "flags"))), "")
-                model += "".join(ln for ln in f if ln.startswith("flags"))[:4000]
-        except OSError:
-            pass
-        out = HERE / "_native" / hashlib.sha1(model.encode()).hexdigest()[:12] / "liboracle_bench.so"
+        out = _native_dir() / "liboracle_bench.so"
         if not out.exists() or out.stat().st_mtime < (HERE / "oracle_bench.c").stat().st_mtime:
             subprocess.run(["make", "-C", str(HERE), f"BENCH_OUT={out}", str(out)], check=True, capture_output=True)
         L = ctypes.CDLL(str(out))
@@ -106,14 +160,24 @@ def bench_lib() -> ctypes.CDLL:
     return _bench_lib
 
 
-def bench(dtype, ni, nk, nj, nthreads, reps, *, gj0=0, gnj=None, seed=12345):
-    """Timed sweeps of the -O3 restatement on a first-touch-correct NI x NK x NJ domain (a j-slab
-    starting at global row gj0 of a domain of gnj rows).  Returns (ms per sweep list, fill seconds)."""
-    L = bench_lib()
+def bench(dtype, ni, nk, nj, nthreads, reps, *, gj0=0, gnj=None, seed=12345, impl="c"):
+    """Timed sweeps on a first-touch-correct NI x NK x NJ domain (a j-slab starting at global row gj0 of
+    a domain of gnj rows) of impl "c" (the -O3 C restatement, gcc + libgomp) or "fortran" (the Fortran
+    CPU path, amdflang + the LLVM OpenMP runtime, which then also does the first touch).  Returns
+    (ms per sweep list, fill seconds).  Do not mix the two impls in one process (two OpenMP runtimes):
+    oracle/cpu_bench.py runs each measurement in its own process."""
     ms = (ctypes.c_double * reps)()
     chk, fill = ctypes.c_double(), ctypes.c_double()
-    rc = L.oracle_bench(np.dtype(dtype).itemsize, ni, nk, nj, gj0, gnj if gnj is not None else nj, seed,
-                        nthreads, reps, ms, ctypes.byref(chk), ctypes.byref(fill))
+    itemsize = np.dtype(dtype).itemsize
+    if impl == "fortran":
+        fn = ctypes.cast(fortran_lib(itemsize, native=True).amt_cpu_fortran, ctypes.c_void_p)
+        rc = bench_llvm_lib().oracle_bench_fn(itemsize, ni, nk, nj, gj0, gnj if gnj is not None else nj, seed,
+                                              nthreads, reps, ms, ctypes.byref(chk), ctypes.byref(fill), fn)
+    elif impl == "c":
+        rc = bench_lib().oracle_bench(itemsize, ni, nk, nj, gj0, gnj if gnj is not None else nj, seed,
+                                      nthreads, reps, ms, ctypes.byref(chk), ctypes.byref(fill))
+    else:
+        raise ValueError(f"unknown impl {impl!r}")
     if rc:
         raise MemoryError(f"oracle_bench: status {rc}")
     if not np.isfinite(chk.value):
@@ -125,13 +189,18 @@ def have_ref(itemsize: int = 8) -> bool:
     return REF_PATHS[itemsize].exists()
 
 
-def _ref_lib(itemsize: int) -> ctypes.CDLL:
-    if itemsize not in _ref_libs:
+def have_ref_nodump(itemsize: int = 8) -> bool:
+    return REF_NODUMP_PATHS[itemsize].exists()
+
+
+def _ref_lib(itemsize: int, nodump: bool = False) -> ctypes.CDLL:
+    key = (itemsize, nodump)
+    if key not in _ref_libs:
         real = ctypes.c_float if itemsize == 4 else ctypes.c_double
-        L = ctypes.CDLL(str(REF_PATHS[itemsize]))
+        L = ctypes.CDLL(str((REF_NODUMP_PATHS if nodump else REF_PATHS)[itemsize]))
         L.ref_advance_mu_t.argtypes, L.ref_advance_mu_t.restype = _sig(real), None
-        _ref_libs[itemsize] = L
-    return _ref_libs[itemsize]
+        _ref_libs[key] = L
+    return _ref_libs[key]
 
 
 def _flags(config_flags):
@@ -206,3 +275,29 @@ def ref_advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, m
             L.ref_advance_mu_t(*args)
         finally:
             os.chdir(old)
+
+
+def ref_nodump_advance_mu_t(*args48):
+    """TIMING ONLY: the reference routine compiled -O3 with its five debug dumps (:175-189) cut out
+    (oracle/_ref/libref_nodump_*.so).  Same argument list; never used for parity."""
+    (ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1, t_ave, ft, mu_tend,
+     rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty, config_flags, *ints) = args48
+    dt, args = _marshal((ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1, t_ave, ft, mu_tend),
+                        (rdx, rdy, dts, epssm), (dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty), config_flags, ints)
+    _ref_lib(dt.itemsize, nodump=True).ref_advance_mu_t(*args)
+
+
+def fortran_advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
+                         t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,
+                         msfuy, msfvx_inv, msftx, msfty, config_flags,
+                         ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme,
+                         its, ite, jts, jte, kts, kte, nthreads: int = 1, native: bool = False):
+    """The Fortran CPU path (oracle/fortran/advance_mu_t_cpu.f90) on numpy arrays, j-tiled over
+    ``nthreads`` OpenMP threads."""
+    dt, args = _marshal((ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,
+                         t_ave, ft, mu_tend), (rdx, rdy, dts, epssm),
+                        (dnw, fnm, fnp, rdnw, msfuy, msfvx_inv, msftx, msfty), config_flags,
+                        (ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte))
+    rc = fortran_lib(dt.itemsize, native=native).amt_cpu_fortran(*args, int(nthreads))
+    if rc:
+        raise ValueError(f"amt_cpu_fortran: status {rc} (2 = bounds outside what the Fortran defines)")

@@ -47,8 +47,26 @@
  * globally).  ms[reps] receives the wall time of each sweep; *checksum a sum over mu (keeps the
  * work observable).  Returns 0, or 1 when the allocation fails, 2 on a bad argument.
  */
-int oracle_bench(int dtype_bytes, int ni, int nk, int nj, long gj0, long gnj, uint64_t seed,
-                 int nthreads, int reps, double *ms, double *checksum, double *fill_seconds)
+/* `fn` (oracle_bench_fn only): NULL = the C restatement, j-tiled here; otherwise a routine with the
+ * argument list of oracle_advance_mu_t_omp_f32/_f64 (arrays, scalars, flags, bounds, nthreads) that tiles
+ * j itself -- the Fortran CPU path, oracle/fortran/advance_mu_t_cpu.f90 (amt_cpu_fortran).  For that
+ * case this file is built with the LLVM OpenMP runtime the Fortran uses (liboracle_bench_llvm.so), so
+ * that the threads that first touch a tile's pages are the threads that compute it. */
+typedef int (*oracle_fn_f32)(float *, const float *, const float *, const float *, const float *, const float *,
+                             float *, const float *, float *, float *, const float *, const float *, float *, float *,
+                             const float *, float *, const float *, const float *, float, float, float, float,
+                             const float *, const float *, const float *, const float *, const float *, const float *,
+                             const float *, const float *, int, int, int, int, int, int, int, int, int, int, int, int,
+                             int, int, int, int, int, int, int, int, int);
+typedef int (*oracle_fn_f64)(double *, const double *, const double *, const double *, const double *, const double *,
+                             double *, const double *, double *, double *, const double *, const double *, double *, double *,
+                             const double *, double *, const double *, const double *, double, double, double, double,
+                             const double *, const double *, const double *, const double *, const double *, const double *,
+                             const double *, const double *, int, int, int, int, int, int, int, int, int, int, int, int,
+                             int, int, int, int, int, int, int, int, int);
+
+int oracle_bench_fn(int dtype_bytes, int ni, int nk, int nj, long gj0, long gnj, uint64_t seed,
+                    int nthreads, int reps, double *ms, double *checksum, double *fill_seconds, void *fn)
 {
     if ((dtype_bytes != 4 && dtype_bytes != 8) || ni < 1 || nk < 1 || nj < 1 || reps < 1 || !ms) return 2;
     if (nthreads < 1) nthreads = 1;
@@ -64,14 +82,21 @@ int oracle_bench(int dtype_bytes, int ni, int nk, int nj, long gj0, long gnj, ui
             return 1;
         }
     }
+    /* a one-thread run has no placement to get right: its fill may use more threads (ORACLE_BENCH_FILL_THREADS) */
+    int fillthreads = nthreads;
+    if (nthreads == 1 && getenv("ORACLE_BENCH_FILL_THREADS")) {
+        fillthreads = atoi(getenv("ORACLE_BENCH_FILL_THREADS"));
+        if (fillthreads < 1) fillthreads = 1;
+        if (fillthreads > nj) fillthreads = nj;
+    }
     const double t_fill = omp_get_wtime();
     /* first touch: thread id fills memory rows of its compute tile (plus the halo rows at the
        two ends); rows are jm = 0 .. jdim-1, compute rows j = 1 .. NJ */
-#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
-    for (int id = 0; id < nthreads; ++id) {
-        long lo = 1 + ((long)nj * id) / nthreads, hi = 1 + ((long)nj * (id + 1)) / nthreads - 1;
+#pragma omp parallel for num_threads(fillthreads) schedule(static, 1)
+    for (int id = 0; id < fillthreads; ++id) {
+        long lo = 1 + ((long)nj * id) / fillthreads, hi = 1 + ((long)nj * (id + 1)) / fillthreads - 1;
         if (id == 0) lo = 0;
-        if (id == nthreads - 1) hi = jdim - 1;
+        if (id == fillthreads - 1) hi = jdim - 1;
         for (int f = 0; f < AMT_F_COUNT; ++f) {
             const int r = amt_field_rank(f);
             if (r == 1) {
@@ -95,12 +120,6 @@ int oracle_bench(int dtype_bytes, int ni, int nk, int nj, long gj0, long gnj, ui
     }
     if (fill_seconds) *fill_seconds = omp_get_wtime() - t_fill;
 
-    for (int rep = 0; rep < reps; ++rep) {
-        const double t0 = omp_get_wtime();
-#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
-        for (int id = 0; id < nthreads; ++id) {
-            const int lo = 1 + (int)(((long)nj * id) / nthreads), hi = 1 + (int)(((long)nj * (id + 1)) / nthreads) - 1;
-            if (hi < lo) continue;
 #define ARGS(T)                                                                                          \
             (T *)a[AMT_F_WW], (T *)a[AMT_F_WW_1], (T *)a[AMT_F_U], (T *)a[AMT_F_U_1], (T *)a[AMT_F_V],  \
             (T *)a[AMT_F_V_1], (T *)a[AMT_F_MU], (T *)a[AMT_F_MUT], (T *)a[AMT_F_MUAVE], (T *)a[AMT_F_MUTS], \
@@ -111,6 +130,21 @@ int oracle_bench(int dtype_bytes, int ni, int nk, int nj, long gj0, long gnj, ui
             (T *)a[AMT_F_MSFUY], (T *)a[AMT_F_MSFVX_INV], (T *)a[AMT_F_MSFTX], (T *)a[AMT_F_MSFTY],      \
             0, 0, 0, 1, ni + 1, 1, nj + 1, nk + 1, 0, ni + 1, 0, nj + 1, 1, nk + 1,                      \
             1, ni + 1, lo, hi, 1, nk + 1
+    for (int rep = 0; rep < reps; ++rep) {
+        const double t0 = omp_get_wtime();
+        if (fn) {
+            const int lo = 1, hi = nj;
+            int rc;
+            if (W == 8) rc = ((oracle_fn_f64)fn)(ARGS(double), nthreads);
+            else rc = ((oracle_fn_f32)fn)(ARGS(float), nthreads);
+            if (rc) { for (int f = 0; f < AMT_F_COUNT; ++f) free(a[f]); return 3; }
+            ms[rep] = (omp_get_wtime() - t0) * 1e3;
+            continue;
+        }
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+        for (int id = 0; id < nthreads; ++id) {
+            const int lo = 1 + (int)(((long)nj * id) / nthreads), hi = 1 + (int)(((long)nj * (id + 1)) / nthreads) - 1;
+            if (hi < lo) continue;
             if (W == 8) (void)oracle_advance_mu_t_f64(ARGS(double));
             else (void)oracle_advance_mu_t_f32(ARGS(float));
 #undef ARGS
@@ -122,4 +156,10 @@ int oracle_bench(int dtype_bytes, int ni, int nk, int nj, long gj0, long gnj, ui
     if (checksum) *checksum = s;
     for (int f = 0; f < AMT_F_COUNT; ++f) free(a[f]);
     return 0;
+}
+
+int oracle_bench(int dtype_bytes, int ni, int nk, int nj, long gj0, long gnj, uint64_t seed,
+                 int nthreads, int reps, double *ms, double *checksum, double *fill_seconds)
+{
+    return oracle_bench_fn(dtype_bytes, ni, nk, nj, gj0, gnj, seed, nthreads, reps, ms, checksum, fill_seconds, NULL);
 }

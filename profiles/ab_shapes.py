@@ -1,7 +1,9 @@
 """In-process A/B of wave shapes of the march kernel on the SAME resident arrays (placement is then
 common to all; interleaved rounds, median and min):
   python profiles/ab_shapes.py --dtype f64 --ni 4096 --nk 80 --nj 2048 auto 1,4,2,0,1 1,4,4,0,1 ...
-a shape is vw,kpt,hl,xd,dma[,jrows[,maxwaves]]; `auto` = the launcher's own choice; `column` = the column kernel.
+a shape is vw,kpt,hl,xd,dma[,jrows[,maxwaves]]; `auto` = the launcher's own choice; `column` = the column kernel;
+`tN` = the launcher's shape with the block schedule N (t0: uniform blocks, t1: the launcher's tapering rule, t48: tapered,
+longest block 48 rows).
 Prints one line per shape: median / min ms, algorithmic TB/s and the fraction of 8 TB/s."""
 import argparse
 import sys
@@ -33,8 +35,13 @@ abytes = np.dtype(dtype).itemsize * a.ni * a.nj * (11 * a.nk + 14)
 
 
 def setup(spec):
+    L.amt_march_set_taper(1)
     if spec == "auto":
         L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
+        return 0
+    if spec[0] == "t":
+        L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
+        L.amt_march_set_taper(int(spec[1:]))
         return 0
     if spec == "column":
         L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
@@ -65,6 +72,7 @@ for rnd in range(a.rounds):
         torch.cuda.synchronize()
         times[spec].append(e0.elapsed_time(e1) / a.inner)
 L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
+L.amt_march_set_taper(1)
 print(f"# {a.ni}x{a.nk}x{a.nj} {a.dtype} idim {b.idim}: {abytes / 1e9:.2f} GB algorithmic per sweep")
 for spec in a.shapes:
     v = times[spec]
@@ -72,4 +80,4 @@ for spec in a.shapes:
         print(f"{spec:>16s}: {names.get(spec)}")
         continue
     med = float(np.median(v))
-    print(f"{spec:>16s}: median {med:8.3f} ms  min {min(v):8.3f}  {abytes / med / 1e9:6.3f} TB/s  {abytes / med / 1e9 / 8:.3f} of 8 TB/s   {names[spec]}")
+    print(f"{spec:>16s}: median {med:8.3f} ms  min {min(v):8.3f}  {abytes / med / 1e9:6.3f} TB/s  {abytes / med / 1e9 / 8:.3f} of 8 TB/s   {names[spec][16:]}")

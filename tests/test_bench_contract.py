@@ -59,3 +59,72 @@ def test_self_launch_without_gpus_fails_fast_and_loud():
                         "--launch-timeout", "120"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "needs a GPU" in (r.stdout + r.stderr)
     assert time.time() - t0 < 120
+
+
+def test_watchdog_returns_raises_and_times_out():
+    import time
+    b = _bench()
+    assert b.watchdog(lambda: 7, 5.0, "quick") == 7
+    try:
+        b.watchdog(lambda: (_ for _ in ()).throw(ValueError("boom")), 5.0, "raises")
+        assert False
+    except ValueError as e:
+        assert "boom" in str(e)
+    t0 = time.time()
+    try:
+        b.watchdog(lambda: time.sleep(30), 0.3, "ncclCommInitRank stand-in")
+        assert False
+    except b.StepTimeout as e:
+        assert "ncclCommInitRank stand-in" in str(e) and time.time() - t0 < 5
+
+
+def test_self_launch_takes_hung_ranks_down_on_sigterm_and_on_timeout():
+    """A rank that never returns must not outlive the launcher: SIGTERM to the parent, or its own
+    --launch-timeout, ends every rank's process group (by pid, never by name)."""
+    import os
+    import re
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["AMT_BENCH_TEST_HANG"] = "300"
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+            return True
+        except ProcessLookupError:
+            return False
+
+    # (a) SIGTERM
+    p = subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--launch-timeout", "200"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    pids, buf = [], ""
+    t_end = time.time() + 60
+    while len(pids) < 2 and time.time() < t_end:
+        line = p.stderr.readline()
+        buf += line
+        pids = [int(x) for x in re.findall(r"pid (\d+) hanging", buf)]
+    assert len(pids) == 2, buf
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=30)
+    assert p.returncode == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    assert not any(alive(q) for q in pids)
+    # (b) the launcher's own timeout
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--launch-timeout", "3"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 124 and "timed out after 3 s" in r.stderr and "[rank 1]" in r.stderr
+    assert time.time() - t0 < 60
+    pids = [int(x) for x in re.findall(r"pid (\d+) hanging", r.stderr)]
+    time.sleep(0.5)
+    assert len(pids) == 2 and not any(alive(q) for q in pids)
+
+
+def test_cpu_baseline_failures_cost_an_entry_not_the_line(monkeypatch, tmp_path):
+    """Every entry of the CPU-baseline leg is a child process under a timeout; a worker that dies is recorded
+    under `errors` and the leg still returns a record (bench.py wraps the whole leg in try/except as well)."""
+    b = _bench()
+    monkeypatch.setattr(b, "ROOT", tmp_path)                 # no oracle/cpu_bench.py there: every child fails
+    out = b.cpu_baseline((64, 8, 32), "f64", 1, 8, 3.0)
+    assert out["value"] is None and out["errors"] and out["kind"] == "port"

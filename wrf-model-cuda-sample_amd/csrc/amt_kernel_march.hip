@@ -99,13 +99,23 @@ static int amt_env_int(const char *name, int dflt)
 #define AMT_CHAIN 10    /* LDS reads kept in flight by the sequential k chains */
 #endif
 
+constexpr int AMT_MAX_SCHED = 30;      // most blocks of one segment of a tapered schedule
+
 struct AmtMarchGrid {
     int ntile_i;     // number of i tiles that hold window columns
-    int tile_lo;     // first such tile
+    int col_lo;      // memory column of the first tile's column 0: the window's first column rounded down to a 128-B line
     int jrows;       // rows per workgroup
     int jstep;       // rows from one j block's first row to the next one's (jrows; edge launches: j1 - j0)
     int njblk;       // number of j blocks
     int nwg;         // ntile_i * njblk
+    // Tapered schedule (nseg = 8, launches of several rounds): the window's rows are cut into one segment per
+    // XCD (seg_rows each), and every segment into nb blocks whose lengths DEcrease -- block b of a segment
+    // covers rows joff[b] .. joff[b+1]-1 of it.  Workgroups are dispatched in blockIdx order, so the long
+    // blocks start first and the short ones fill in at the end: the launch's tail (compute units that have
+    // run out of work while others still march through a whole block) shrinks from about half a long block
+    // to half a short one.  nseg = 0: uniform blocks of jrows rows (small launches, edge launches).
+    int nseg, seg_rows, nb;
+    unsigned short joff[AMT_MAX_SCHED + 1];
 };
 
 // ---------------------------------------------------------------------------
@@ -314,14 +324,30 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
     // dispatch), so give each XCD a contiguous run of logical ids: neighbouring i-tiles
     // of one j block then run on one XCD at about the same time and share the tile-edge
     // cache lines in that XCD's L2.  Speed only, never correctness.
-    int lid;
-    {
+    int lid, ja, jb;
+    if (g.nseg) {
+        // tapered schedule: XCD x = blockIdx % 8 owns segment x; its workgroups come in the order of y
+        const int x = blockIdx.x % 8, y = blockIdx.x / 8;
+        const int blk = y / g.ntile_i;
+        lid = y % g.ntile_i;                      // the tile
+        ja = p.j0 + x * g.seg_rows + g.joff[blk];
+        jb = p.j0 + x * g.seg_rows + g.joff[blk + 1] - 1;
+        const int jlast = (x + 1) * g.seg_rows - 1 < p.j1 - p.j0 ? p.j0 + (x + 1) * g.seg_rows - 1 : p.j1;
+        if (jb > jlast) jb = jlast;
+        if (ja > jb) return;                      // the last segment may be short (before any barrier: the whole workgroup leaves)
+    } else {
         const int nx = 8, q = g.nwg / nx, r = g.nwg % nx;
         const int x = blockIdx.x % nx, y = blockIdx.x / nx;
         lid = x * q + (x < r ? x : r) + y;        // XCD x owns q (+1 if x < r) consecutive ids
+        const int jblk = lid / g.ntile_i;
+        ja = p.j0 + jblk * g.jstep;
+        jb = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
     }
-    const int tile = g.tile_lo + lid % g.ntile_i;
-    const int jblk = lid / g.ntile_i;
+    // Tiles are anchored at the WINDOW (its first column rounded down to a 128-byte line of the row), not
+    // at multiples of TC from the row start: a window that starts 32 elements into a row (the resident
+    // layout) would otherwise straddle one more, half-empty tile (512x60x512: 9 x 27 = 243 workgroups on
+    // 256 CUs instead of 8 x 32).  Neither the LDS-DMA nor the plain loads need more than line alignment.
+    const int col0 = g.col_lo + (lid % g.ntile_i) * TC;
 
     for (int e = threadIdx.x; e < 4 * nkr; e += blockDim.x) {
         const int which = e & 3, k = e >> 2;
@@ -329,15 +355,13 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         S1[e] = src[p.k1 + (k < nk ? k : nk - 1)];
     }
 
-    const int ja   = p.j0 + jblk * g.jstep;
-    const int jb   = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
     const long idim = p.idim, js = p.jstride;
     const unsigned lev = (unsigned)idim * W;                  // byte step of one level
     const unsigned row3 = (unsigned)js * W;                   // byte step of one j row (3-D)
     const unsigned row2 = lev;                                // byte step of one j row (2-D)
-    const long e2 = (long)ja * idim + (long)tile * TC;        // (column 0 of the tile, row ja)
-    const bool halo_l_mem = tile * TC - 1 >= 0;               // the tile's left / right neighbour column exists
-    const bool halo_r_mem = tile * TC + TC < p.idim;
+    const long e2 = (long)ja * idim + (long)col0;        // (column 0 of the tile, row ja)
+    const bool halo_l_mem = col0 - 1 >= 0;               // the tile's left / right neighbour column exists
+    const bool halo_r_mem = col0 + TC < p.idim;
 
     // The 2-D inputs of a row are fetched ONCE per workgroup, one row ahead, by the column
     // wave and handed to the cell waves through LDS.  Slot order of D2:
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         // column wave: lanes 0..TI-1 own the tile's columns (VW each)
         // =====================================================================
         const int c = lane * VW;
-        const int ii = tile * TC + c;
+        const int ii = col0 + c;
         const bool own = lane < TI;
         const bool inmem = own && (ii + VW <= p.idim);
         const bool tail = VW > 1 && own && !inmem && ii < p.idim;  // odd row length: my first column is the row's last
@@ -371,7 +395,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         }
         const bool halo_r = (lane == 0) && halo_r_mem;         // lane 0 also fetches element TC
         const unsigned vo = (unsigned)c * W;
-        const T *wwin_b = p.ww + (long)ja * js + (long)p.k1 * idim + (long)tile * TC;   // level 1
+        const T *wwin_b = p.ww + (long)ja * js + (long)p.k1 * idim + (long)col0;   // level 1
         const T *mut_b = p.mut + e2;
         T *mu_b = p.mu + e2, *mudf_b = p.mudf + e2, *muts_b = p.muts + e2, *muave_b = p.muave + e2;
         const T dts = p.dts;
@@ -465,7 +489,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         // =====================================================================
         const int il = lane % TI, h = lane / TI;
         const int c = il * VW;                             // first of my columns within the tile
-        const int ii = tile * TC + c;
+        const int ii = col0 + c;
         const bool inmem = ii + VW <= p.idim;              // my columns lie inside the memory row
         bool on[VW], act = false, all = true;              // which of them are window columns
 #pragma unroll
@@ -489,7 +513,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         // the tile, the wave's first level, row ja) of every 3-D array.  The column, the level group,
         // the level step and the row advance go into a 32-bit per-lane byte offset, which the
         // launcher keeps below 2^31.
-        const long e3 = (long)ja * js + (long)(p.k1 + kfw) * idim + (long)tile * TC;
+        const long e3 = (long)ja * js + (long)(p.k1 + kfw) * idim + (long)col0;
         const T *u_b = p.u + e3, *u1_b = p.u_1 + e3, *ft_b = p.ft + e3, *ww1_b = p.ww_1 + e3;
         const T *t1_b = p.t_1 + e3, *v_b = p.v + e3, *v1_b = p.v_1 + e3;   // row ja
         T *t_b = p.t + e3, *tave_b = p.t_ave + e3, *ww_b = p.ww + e3;
@@ -515,7 +539,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         auto dma_rows = [&](int ln, const T *src, int rows, T *lds) {
             const int dl = ln / LPL;                                         // level within the instruction
             const unsigned dch = (unsigned)(ln % LPL) * 16u;                 // my 16-byte chunk of the row
-            const bool dok = tile * TC + (ln % LPL) * EPL < p.idim;          // chunk lies inside the memory row
+            const bool dok = col0 + (ln % LPL) * EPL < p.idim;          // chunk lies inside the memory row
             if constexpr (LW % LPI == 0) {
                 // a wave fetches the levels it computes
 #pragma unroll
@@ -965,10 +989,11 @@ template <typename T> static AmtMarchEntry<T> *amt_march_find(const AmtMarchShap
 // that walk every instantiation; 0 / -1 leave a parameter to the launcher.
 struct AmtMarchEnv {
     int dma, kpt, hl, vw, xd, jrows, verbose, wm;
+    int taper;       // tapered block schedule: 0 off, 1 the launcher's rule, > 1 the longest block in rows
 };
-static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0};
+static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 1};
 // The instantiation the last plan of the calling thread chose (diagnosis / tests): "" before any launch.
-static thread_local char g_march_last[160] = "";
+static thread_local char g_march_last[360] = "";
 extern "C" const char *amt_march_last_kernel(void) { return g_march_last; }
 void amt_march_note_kernel(const char *name) { snprintf(g_march_last, sizeof g_march_last, "%s", name); }   // amt_api.hip: column kernel
 static int g_march_generation = 0;                 // bumped by amt_march_force_shape: cached plans are stale
@@ -979,7 +1004,8 @@ static const AmtMarchEnv &amt_march_env()
         g_march_env = {amt_env_int("AMT_MARCH_DMA", 1), amt_env_int("AMT_MARCH_KPT", 0),
                        amt_env_int("AMT_MARCH_HL", 0), amt_env_int("AMT_MARCH_VW", 0),
                        amt_env_int("AMT_MARCH_XD", -1), amt_env_int("AMT_MARCH_JROWS", 0),
-                       amt_env_int("AMT_MARCH_VERBOSE", 0), amt_env_int("AMT_MARCH_WM", 0)};
+                       amt_env_int("AMT_MARCH_VERBOSE", 0), amt_env_int("AMT_MARCH_WM", 0),
+                       amt_env_int("AMT_MARCH_TAPER", 1)};
     });
     return g_march_env;
 }
@@ -996,6 +1022,38 @@ extern "C" int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, i
     g_march_env.wm = wm > 0 ? wm : 0;
     ++g_march_generation;
     return 0;
+}
+
+extern "C" int amt_march_set_taper(int taper)
+{
+    (void)amt_march_env();
+    g_march_env.taper = taper < 0 ? 0 : taper;
+    ++g_march_generation;
+    return 0;
+}
+
+// Tapered schedule of one segment of `seg` rows: main blocks of about lmax rows, then halving ones down to
+// lmin.  Returns the number of blocks (0: does not fit AMT_MAX_SCHED); joff[0..nb] are the block starts.
+static int amt_march_taper(int seg, int lmax, int lmin, unsigned short *joff)
+{
+    int tail[16], nt = 0, tsum = 0;
+    if (lmax > seg) lmax = seg;
+    if (lmin > lmax) lmin = lmax;
+    for (int t = lmax / 2; t >= lmin && nt < 14; t /= 2) { tail[nt++] = t; tsum += t; }
+    if (nt && tsum + lmin <= seg) { tail[nt++] = lmin; tsum += lmin; }
+    while (nt && tsum > seg) tsum -= tail[--nt];                    // (cannot happen: tsum <= lmax <= seg)
+    int mainrows = seg - tsum;
+    if (nt && mainrows > 0 && mainrows < lmin) { tail[0] += mainrows; mainrows = 0; }   // no sliver of a first block
+    const int nmain = mainrows > 0 ? (mainrows + lmax - 1) / lmax : 0;
+    if (nmain + nt > AMT_MAX_SCHED || nmain + nt < 1) return 0;
+    int nb = 0, at = 0;
+    for (int b = 0; b < nmain; ++b) {
+        joff[nb++] = (unsigned short)at;
+        at += mainrows / nmain + (b < mainrows % nmain ? 1 : 0);
+    }
+    for (int b = 0; b < nt; ++b) { joff[nb++] = (unsigned short)at; at += tail[b]; }
+    joff[nb] = (unsigned short)at;                                  // = seg
+    return nb;
 }
 
 // Rows per workgroup.  A block costs its rows plus a prologue (4 extra array-rows of loads, about
@@ -1025,6 +1083,16 @@ static int amt_march_rows(long ntile_i, int nj, int cus, double *cost_out, long 
 // registers per lane first -- 4 levels per lane is what fits 127 VGPRs in fp64 (and in fp32 with two
 // columns per lane) without scratch; more levels come from splitting the wave into level groups
 // (HL), never from more levels per lane.  The DMA flavour wherever the layout allows it.
+// Column 0 of the first i tile: the window's first column rounded down to a 128-byte line of the memory
+// row (16 fp64 / 32 fp32 elements), so that a tile's plain loads and stores start on a line whenever the
+// rows themselves do.
+static int amt_march_cus(int dev);
+template <typename T> static int amt_march_col_lo(const AmtParams<T> &p)
+{
+    const int line = 128 / (int)sizeof(T);
+    return p.i0 / line * line;
+}
+
 template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarchShape &out)
 {
     const int nk = p.nk;
@@ -1087,12 +1155,12 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
         // (profiles/r02_small_domains.md: 64x40x64 11 -> 9 us, 128x60x128 fp64 30 -> 23 us), while in
         // a launch of several rounds it moves fewer bytes per second (512x60x512: 1.17x the time).
         {
-            const int nj = p.edges ? 2 : p.j1 - p.j0 + 1, cus = 256;
+            const int nj = p.edges ? 2 : p.j1 - p.j0 + 1, cus = amt_march_cus(-1);
             auto model = [&](const AmtMarchShape &q) {
                 const int tc = (64 / q.hl) * q.vw;
                 double c = 0;
                 long rounds = 1;
-                amt_march_rows(p.i1 / tc - p.i0 / tc + 1, nj, cus, &c, &rounds);
+                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, &c, &rounds);
                 return c * (q.hl == out.hl ? 1.0 : rounds == 1 ? 0.8 : 1.2);
             };
             if (out.hl < 4)
@@ -1129,11 +1197,14 @@ template <typename T> struct AmtMarchPlan {
     int full, nw;
     size_t lds;
     AmtMarchGrid grid;
+    char label[360];       // instantiation, rows per workgroup, schedule: what amt_march_last_kernel reports
 };
 
+// compute units of device `dev` (-1: the current device); 256 when no device answers
 static int amt_march_cus(int dev)
 {
     static int cus[64] = {};
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
     const int slot = (dev >= 0 && dev < 64) ? dev : 0;
     if (cus[slot] == 0) {
         hipDeviceProp_t prop;
@@ -1160,8 +1231,8 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
     pl.lds = amt_march_lds_bytes((int)sizeof(T), s, p.nk);
     AmtMarchGrid &g = pl.grid;
     const int nj = p.j1 - p.j0 + 1;
-    g.tile_lo = p.i0 / tc;
-    g.ntile_i = p.i1 / tc - g.tile_lo + 1;
+    g.col_lo = amt_march_col_lo(p);
+    g.ntile_i = (p.i1 - g.col_lo) / tc + 1;
     int jrows = env.jrows;
     if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), nullptr, nullptr);
     if (jrows > nj) jrows = nj;
@@ -1175,6 +1246,26 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
         g.njblk = 2;
     }
     g.nwg = g.ntile_i * g.njblk;
+    g.nseg = 0; g.seg_rows = 0; g.nb = 0;
+    memset(g.joff, 0, sizeof g.joff);
+    if (!p.edges && env.jrows < 1 && env.taper) {
+        // Launches of several rounds: one segment of rows per XCD, blocks of decreasing length (see AmtMarchGrid).
+        // Worth it when a segment keeps its XCD's compute units busy for at least two rounds of the longest blocks.
+        const int cpx = amt_march_cus(pl.dev) / 8 > 0 ? amt_march_cus(pl.dev) / 8 : 1;
+        const int seg = (nj + 7) / 8;
+        int lmax = env.taper > 1 ? env.taper : 64;
+        if (lmax > max_rows) lmax = (int)max_rows;
+        if (lmax > seg) lmax = seg;
+        const bool enough = env.taper > 1 || (long)g.ntile_i * seg >= 2L * cpx * lmax;
+        if (enough && seg >= 16 && seg < 65536) {
+            const int nb = amt_march_taper(seg, lmax, lmax < 8 ? lmax : 8, g.joff);
+            if (nb > 0) {
+                g.nseg = 8; g.seg_rows = seg; g.nb = nb;
+                g.nwg = 8 * nb * g.ntile_i;
+                g.jrows = lmax;                       // reporting only
+            }
+        }
+    }
     if (pl.lds > 64 * 1024 && !(pl.entry->lds_granted[pl.full] >> (pl.dev & 31) & 1u)) {
         // the attribute is per device and per kernel instantiation: allow all of the CU's LDS once
         // (what a launch occupies is its own dynamic size, not this ceiling)
@@ -1182,10 +1273,19 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
         if (e != hipSuccess) { (void)hipGetLastError(); return false; }
         pl.entry->lds_granted[pl.full] |= 1u << (pl.dev & 31);
     }
+    char sched[200] = "";
+    if (g.nseg) {
+        int at = snprintf(sched, sizeof sched, " tapered 8 x [");
+        for (int b = 0; b < g.nb && at < (int)sizeof sched - 12; ++b)
+            at += snprintf(sched + at, sizeof sched - at, "%s%d", b ? " " : "", g.joff[b + 1] - g.joff[b]);
+        snprintf(sched + at, sizeof sched - at, "]");
+    }
     if (env.verbose)
-        fprintf(stderr, "[amt march] nk %d idim %d window i %d..%d, %d rows -> %s %s: %d waves, %zu B LDS, %d tiles x %d blocks of %d rows\n",
-                p.nk, p.idim, p.i0, p.i1, nj, pl.entry->name, pl.full ? "FULL" : "ragged", pl.nw, pl.lds, g.ntile_i, g.njblk, g.jrows);
-    snprintf(g_march_last, sizeof g_march_last, "%s %s jrows=%d", pl.entry->name, pl.full ? "FULL" : "ragged", g.jrows);
+        fprintf(stderr, "[amt march] nk %d idim %d window i %d..%d, %d rows -> %s %s: %d waves, %zu B LDS, %d tiles x %d blocks of %d rows%s\n",
+                p.nk, p.idim, p.i0, p.i1, nj, pl.entry->name, pl.full ? "FULL" : "ragged", pl.nw, pl.lds, g.ntile_i,
+                g.nseg ? 8 * g.nb : g.njblk, g.jrows, sched);
+    snprintf(pl.label, sizeof pl.label, "%s %s jrows=%d%s", pl.entry->name, pl.full ? "FULL" : "ragged", g.jrows, sched);
+    snprintf(g_march_last, sizeof g_march_last, "%s", pl.label);
     pl.ok = true;
     return true;
 }
@@ -1227,6 +1327,8 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
     const AmtMarchPlan<T> *pl = amt_march_plan<T>(p);
     if (!pl) return hipErrorNotSupported;
     pl->entry->launch[pl->full](stream, p, pl->grid, pl->nw, pl->lds);
+    // the kernel the calling thread LAUNCHED last (a slab's one-row edge launch does not rename its interior kernel)
+    if (!p.edges && strcmp(g_march_last, pl->label) != 0) snprintf(g_march_last, sizeof g_march_last, "%s", pl->label);
     return hipGetLastError();
 }
 

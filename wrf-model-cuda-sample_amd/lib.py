@@ -70,6 +70,7 @@ SYMBOLS = {
     "amt_synth_fill_host": (_I, [_I, _I, _P, ctypes.c_uint64] + [_L] * 9),
     "amt_synth_fill_device": (_I, [_P, _I, _I, _P, ctypes.c_uint64] + [_L] * 9),
     "amt_calib_stream_copy": (_I, [_P, _P, _P, ctypes.c_size_t, _I]),
+    "amt_calib_stream_rate": (_I, [_P, _P, _P, ctypes.c_size_t, _I]),
     "amt_host_pin": (_I, [_P, ctypes.c_size_t]),
     "amt_host_unpin": (_I, [_P]),
     "amt_host_release": (_I, []),
@@ -88,6 +89,7 @@ SYMBOLS = {
     "amt_slab_barrier": (_I, [_P]),
     "amt_slab_max": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
     "amt_march_force_shape": (_I, [_I] * 7),
+    "amt_march_set_taper": (_I, [_I]),
     "amt_march_last_kernel": (ctypes.c_char_p, []),
     "amt_march_selectable": (_I, [ctypes.c_char_p, _I]),
 }
