@@ -108,12 +108,14 @@ struct AmtMarchGrid {
     int jstep;       // rows from one j block's first row to the next one's (jrows; edge launches: j1 - j0)
     int njblk;       // number of j blocks
     int nwg;         // ntile_i * njblk
-    // Tapered schedule (nseg = 8, launches of several rounds): the window's rows are cut into one segment per
-    // XCD (seg_rows each), and every segment into nb blocks whose lengths DEcrease -- block b of a segment
-    // covers rows joff[b] .. joff[b+1]-1 of it.  Workgroups are dispatched in blockIdx order, so the long
-    // blocks start first and the short ones fill in at the end: the launch's tail (compute units that have
-    // run out of work while others still march through a whole block) shrinks from about half a long block
-    // to half a short one.  nseg = 0: uniform blocks of jrows rows (small launches, edge launches).
+    // Tapered schedule (nseg = 8; opt-in, AMT_MARCH_TAPER / amt_march_set_taper): the window's rows are cut
+    // into one segment per XCD (seg_rows each), and every segment into nb blocks whose lengths DEcrease -- block
+    // b of a segment covers rows joff[b] .. joff[b+1]-1 of it.  Workgroups are dispatched in blockIdx order, so
+    // the long blocks start first and the short ones fill in at the end: meant to shorten the launch's tail.
+    // MEASURED (profiles/r03_block_schedule.md): 0.2 .. 2.5 % SLOWER than uniform 64-row blocks at every size
+    // from 4096x60x512 to 4096x60x4096 in both precisions -- the launch's fixed cost (about 0.3 ms) is not a
+    // tail of unevenly finishing workgroups -- so it is off by default and kept as the experiment it was.
+    // nseg = 0: uniform blocks of jrows rows.
     int nseg, seg_rows, nb;
     unsigned short joff[AMT_MAX_SCHED + 1];
 };
@@ -989,9 +991,9 @@ template <typename T> static AmtMarchEntry<T> *amt_march_find(const AmtMarchShap
 // that walk every instantiation; 0 / -1 leave a parameter to the launcher.
 struct AmtMarchEnv {
     int dma, kpt, hl, vw, xd, jrows, verbose, wm;
-    int taper;       // tapered block schedule: 0 off, 1 the launcher's rule, > 1 the longest block in rows
+    int taper;       // tapered block schedule (an experiment that lost): 0 off (default), 1 the rule, > 1 the longest block in rows
 };
-static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 1};
+static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 0};
 // The instantiation the last plan of the calling thread chose (diagnosis / tests): "" before any launch.
 static thread_local char g_march_last[360] = "";
 extern "C" const char *amt_march_last_kernel(void) { return g_march_last; }
@@ -1005,7 +1007,7 @@ static const AmtMarchEnv &amt_march_env()
                        amt_env_int("AMT_MARCH_HL", 0), amt_env_int("AMT_MARCH_VW", 0),
                        amt_env_int("AMT_MARCH_XD", -1), amt_env_int("AMT_MARCH_JROWS", 0),
                        amt_env_int("AMT_MARCH_VERBOSE", 0), amt_env_int("AMT_MARCH_WM", 0),
-                       amt_env_int("AMT_MARCH_TAPER", 1)};
+                       amt_env_int("AMT_MARCH_TAPER", 0)};
     });
     return g_march_env;
 }
