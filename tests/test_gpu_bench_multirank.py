@@ -83,3 +83,32 @@ def test_single_gpu_line_carries_the_contract_keys():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "traffic_source" in rf
     assert out["cpu_baseline"]["kind"] in ("port", "reference") and out["cpu_baseline"]["cores"] >= 1
+    # the CPU baseline is the Fortran CPU path, one child process per entry
+    cb = out["cpu_baseline"]
+    assert cb["impl"].startswith("fortran") and cb["value"] and cb["value"] > 0
+    assert any(m["impl"] == "fortran" and m["threads"] == 1 for m in cb["matrix"])
+    # attribution: this box's own streaming rates and what they make of the launch
+    for key in ("box_copy_GBps", "box_read_GBps", "box_mixed_ceiling_ms", "frac_of_box_copy", "frac_of_box_mixed"):
+        assert key in rf and rf[key] > 0, key
+    assert 2000 < rf["box_copy_GBps"] < 8000 and rf["box_read_GBps"] >= 0.9 * rf["box_copy_GBps"]
+    assert "gpu_state" in out
+    assert out["config"]["placement_probe_ms"] is None or len(out["config"]["placement_probe_ms"]) >= 2
+
+
+def test_two_ranks_on_one_device_over_rccl_end_with_a_diagnosis_not_a_hang():
+    """The first contact with RCCL happens on the driver's clock: whatever goes wrong there must end every
+    rank, non-zero, with what it knows, well inside --comm-timeout.  Two ranks on ONE device is the failure this
+    box can produce: ncclCommInitRank refuses (or blocks) and so does torch.distributed's own group."""
+    import time
+    if _gpus() >= 2:
+        pytest.skip("two devices visible: the real two-rank tests run instead")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-gpu", "--comm-timeout", "40",
+                        "--launch-timeout", "300", "--no-box-probe", "--probe-placements", "1"] + SMALL,
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    took = time.time() - t0
+    assert r.returncode != 0, r.stdout[-1000:]
+    assert "FATAL" in r.stderr and "[rank " in r.stderr, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no measurement line may come out of a failed launch"
+    assert took < 280, took

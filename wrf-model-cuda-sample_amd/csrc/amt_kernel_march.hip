@@ -98,6 +98,16 @@ static int amt_env_int(const char *name, int dflt)
 #ifndef AMT_CHAIN
 #define AMT_CHAIN 10    /* LDS reads kept in flight by the sequential k chains */
 #endif
+// PRICING builds only (wrong results; profiles/r03_column_wave_pricing.md): what would a schedule be worth that
+// halves the column wave's chain time per row (two rows' chains side by side on the 64 lanes) or the number of
+// barriers per row?  AMT_DIAG_CHAIN_DIV n: both k chains run over nk / n levels.  AMT_DIAG_FEWER_BARRIERS 1:
+// barriers 2 and 3 (the LDS-only ones) are dropped in every wave.
+#ifndef AMT_DIAG_CHAIN_DIV
+#define AMT_DIAG_CHAIN_DIV 1
+#endif
+#ifndef AMT_DIAG_FEWER_BARRIERS
+#define AMT_DIAG_FEWER_BARRIERS 0
+#endif
 
 constexpr int AMT_MAX_SCHED = 30;      // most blocks of one segment of a tapered schedule
 
@@ -266,7 +276,11 @@ constexpr int AMT_N2D = 7;    // staged 2-D rows: msftx msfty muu msfuy muv' msf
 
 __device__ __forceinline__ void amt_lds_barrier()
 {
+#if AMT_DIAG_FEWER_BARRIERS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 
@@ -438,16 +452,17 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             if (own) { mu_tend = amt_ldsv<T, VW>(D2 + 6 * TW + c); msfty_c = amt_ldsv<T, VW>(D2 + 1 * TW + c); }
             __syncthreads();                                     // 1: AB complete, D2/T1 row j no longer read
             V dmdt(T(0));
+            const int nkc = nk / AMT_DIAG_CHAIN_DIV;             // = nk in every product build
             if (own) {                                           // :147, sequential in k
                 int k = 0;
-                for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
+                for (; k + AMT_CHAIN <= nkc; k += AMT_CHAIN) {
                     V a[AMT_CHAIN];
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) a[q] = s_dnw(k + q) * amt_ldsv<T, VW>(AB + (k + q) * TC + c);
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) dmdt = dmdt + a[q];
                 }
-                for (; k < nk; ++k) dmdt = dmdt + s_dnw(k) * amt_ldsv<T, VW>(AB + k * TC + c);
+                for (; k < nkc; ++k) dmdt = dmdt + s_dnw(k) * amt_ldsv<T, VW>(AB + k * TC + c);
                 // with dmdt: this row's mu_tend and msfty, for the cell waves' P2 and P3 (D2 moves on to
                 // row j+1 below; these stay until the column wave passes barrier 1 of the next row)
                 amt_stsv<T, VW>(DM + c, dmdt);
@@ -474,14 +489,14 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             if (own) {                                           // :161, sequential in k; AB[k] <- ww(k), the value BEFORE increment k
                 V wwu = ww1in;
                 int k = 0;
-                for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
+                for (; k + AMT_CHAIN <= nkc; k += AMT_CHAIN) {
                     V b[AMT_CHAIN];
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) b[q] = amt_ldsv<T, VW>(AB + (k + q) * TC + c);
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) { amt_stsv<T, VW>(AB + (k + q) * TC + c, wwu); wwu = wwu - b[q]; }
                 }
-                for (; k < nk; ++k) { const V bk = amt_ldsv<T, VW>(AB + k * TC + c); amt_stsv<T, VW>(AB + k * TC + c, wwu); wwu = wwu - bk; }
+                for (; k < nkc; ++k) { const V bk = amt_ldsv<T, VW>(AB + k * TC + c); amt_stsv<T, VW>(AB + k * TC + c, wwu); wwu = wwu - bk; }
             }
             __syncthreads();                                     // 4: ww of the recurrence published (DMA landed)
         }
