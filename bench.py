@@ -273,8 +273,10 @@ def cpu_baseline(dims, dtype_name, seed, rows, seconds):
         cmd = [sys.executable, worker, "--impl", impl, "--dtype", dtype_name, "--size", *map(str, shape),
                "--threads", str(threads), "--seconds", f"{budget:.2f}", "--seed", str(seed), "--gj0", str(gj0), "--gnj", str(gnj)]
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(20.0, 4 * left),
-                               env=dict(os.environ, ORACLE_BENCH_FILL_THREADS=str(cores)))
+            # (no ORACLE_BENCH_FILL_THREADS for the one-thread entries: on a two-socket host the pages a parallel
+            # fill touches land on both sockets and the single compute thread then reads half its data remotely:
+            # 151 against 229 Mcells/s for the same code on 2 x EPYC 9575F)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(20.0, 4 * left))
             if r.returncode != 0:
                 raise RuntimeError(f"exit {r.returncode}: {r.stderr.strip()[-300:]}")
             rec = json.loads(r.stdout.strip().splitlines()[-1])
@@ -419,7 +421,8 @@ def self_launch(a):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
                        LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                        AMT_RENDEZVOUS_NONCE=nonce, AMT_BENCH_SELF_LAUNCHED="1")
-            env.setdefault("NCCL_DEBUG", "WARN")
+            if env.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":     # unset, or the image's quiet default
+                env["NCCL_DEBUG"] = "WARN"
             p = subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
                                  stdout=None if r == 0 else subprocess.PIPE, stderr=subprocess.PIPE,
                                  start_new_session=True)
