@@ -803,7 +803,7 @@ def run_rank(a):
             cp, rdr = ceilings["box_copy_GBps"], ceilings["box_read_GBps"]
             inv_w = 2.0 / cp - 1.0 / rdr                                   # seconds per GB written
             mixed_ms = (rd_bytes / rdr + wr_bytes * max(inv_w, 1.0 / rdr)) / 1e6
-            moved = (traffic / world if traffic and world > 1 else traffic) or (rd_bytes + wr_bytes)
+            moved = traffic or (rd_bytes + wr_bytes)              # N > 1 records are per rank and sweep already
             out["roofline"].update({
                 "box_copy_GBps": cp, "box_read_GBps": rdr,
                 "box_write_GBps_inferred": round(1.0 / max(inv_w, 1.0 / rdr), 1),

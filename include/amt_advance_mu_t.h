@@ -130,6 +130,23 @@ int amt_host_unpin(void *ptr);
  * workspace now; it is freed anyway when the thread ends. */
 int amt_host_release(void);
 
+/* Residency cache of the one-shot calls (per calling host thread; off by default).  In WRF's acoustic loop
+ * (solve_em) advance_mu_t is called number_of_small_timesteps times per Runge-Kutta stage with the SAME
+ * ww_1, u_1, v_1, t_1 (the `_save` linearisation state) and ft (the tendency): five of the eight 3-D arrays a
+ * call uploads.  With the cache enabled the calling thread keeps whole-window device copies of these five
+ * between calls -- keyed on their host addresses and every extent -- and uploads one again only after
+ * amt_host_invalidate(ptr) (NULL: all of them; call it when a new RK stage has rewritten them, and when an
+ * array was freed and another one allocated at the same address: the key is the address, not the contents).  u, v, t, mu
+ * and level 1 of ww, which change from sub-step to sub-step, the 2-D and 1-D arrays (1/NK of the data) and all
+ * outputs cross the link on every call as before.  The reference re-uploads everything on every call
+ * (advance_mu_t_no_async.cu:245-306).
+ * amt_host_cache_check(1) is the debug mode: every call checksums the cached arrays on the host and fails with
+ * AMT_ERR_PRECONDITION if one changed without an invalidate (it reads the whole arrays: slow).
+ * amt_host_cache_enable(0) and amt_host_release() free the copies. */
+int amt_host_cache_enable(int on);
+int amt_host_cache_check(int on);
+int amt_host_invalidate(const void *host_ptr);
+
 /* ------------------------------------------------------------------------
  * (2) Device-resident drop-ins: the same call with every array pointer in
  *     DEVICE memory of the current device, enqueued on `hip_stream`

@@ -51,7 +51,8 @@ def test_tenth_of_the_rows_of_configs2_against_the_oracle(pkg, oracle):
     # chunk starts: both domain edges, and chunks whose middle is a j-block boundary (first rows of
     # a workgroup's block come out of its prologue, the last ones end its march)
     first_row = 2                                              # specified: j_start = jds + 1
-    bnd = [first_row + jrows * k for k in (1, 17, 40, 63, 90, 111)]
+    nblk = -(-(dims[2] - 2) // jrows)                           # uniform blocks of jrows rows from first_row
+    bnd = [first_row + jrows * k for k in sorted({1, nblk // 6, nblk // 3, nblk // 2, (2 * nblk) // 3, nblk - 2})]
     starts = [1, dims[2] - rows + 1] + [x - rows // 2 for x in bnd if x + rows // 2 <= dims[2]]
     threads = max(1, min(len(os.sched_getaffinity(0)), rows))
     checked = set()

@@ -138,3 +138,18 @@ def advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf,
 
 
 advance_mu_t.bind = bind_device_call        # SlabStepper pre-marshals its per-sweep launches through this
+
+
+def host_cache_enable(on: bool = True, check: bool = False) -> None:
+    """Residency cache of the one-shot (numpy) calls of the calling thread: ww_1, u_1, v_1, t_1, ft stay on the
+    device between calls (header section 1: amt_host_cache_enable).  ``check``: the checksum debug mode."""
+    L = _lib.load_library()
+    _lib.check(L.amt_host_cache_enable(int(bool(on))))
+    _lib.check(L.amt_host_cache_check(int(bool(check))))
+
+
+def host_invalidate(array=None) -> None:
+    """The host array (numpy) changed since the last call: upload it again.  None: all cached arrays."""
+    L = _lib.load_library()
+    ptr = None if array is None else array.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(L.amt_host_invalidate(ptr))

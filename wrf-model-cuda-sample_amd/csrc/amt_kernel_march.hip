@@ -1104,9 +1104,13 @@ static int amt_march_rows(long ntile_i, int nj, int cus, double *cost_out, long 
 // row (16 fp64 / 32 fp32 elements), so that a tile's plain loads and stores start on a line whenever the
 // rows themselves do.
 static int amt_march_cus(int dev);
+// Rows that are not whole lines (WRF's own ims:ime = its-1:ite+1: 4098 elements) put every level row at
+// another phase of the line anyway: there the tiles start AT the window, which saves the 65th tile that a
+// window starting one element into the row would otherwise leave with a single column.
 template <typename T> static int amt_march_col_lo(const AmtParams<T> &p)
 {
     const int line = 128 / (int)sizeof(T);
+    if (p.idim % line != 0) return p.i0;
     return p.i0 / line * line;
 }
 

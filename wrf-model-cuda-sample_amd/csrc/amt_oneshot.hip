@@ -29,6 +29,28 @@ struct HostWorkspace {
     size_t stage_size = 0;
     static constexpr size_t keep_limit = (size_t)1 << 30;   // larger arenas are not kept between calls
 
+    // Residency cache (amt_host_cache_enable): whole-window device copies of the five 3-D inputs that are
+    // constant over the acoustic sub-steps of a Runge-Kutta stage -- ww_1, u_1, v_1, t_1, ft -- kept between
+    // calls and uploaded again only after amt_host_invalidate.  Keyed on the host pointers and every extent.
+    static constexpr int NRES = 5;
+    struct Resident {
+        bool enabled = false, check = false;
+        char *buf[NRES] = {};
+        size_t bytes_each = 0;
+        bool valid[NRES] = {};
+        uint64_t sum[NRES] = {};                              // checksum of what was uploaded (check mode)
+        const void *host[NRES] = {};
+        int key[16] = {};                                     // element size, extents, window rows
+        void drop()
+        {
+            for (int r = 0; r < NRES; ++r) {
+                if (buf[r]) (void)hipFree(buf[r]);
+                buf[r] = nullptr; valid[r] = false; host[r] = nullptr; sum[r] = 0;
+            }
+            bytes_each = 0;
+        }
+    } res;
+
     void release()
     {
         if (device < 0) return;
@@ -41,8 +63,11 @@ struct HostWorkspace {
                 if (e) (void)hipEventDestroy(e);
         if (arena) (void)hipFree(arena);
         if (stage) (void)hipHostFree(stage);
+        const bool en = res.enabled, ck = res.check;
+        res.drop();
         if (sw) (void)hipSetDevice(prev);
         *this = HostWorkspace();
+        res.enabled = en; res.check = ck;                    // settings of the thread outlive its buffers
     }
     // A worker thread's workspace is freed when the thread ends.  The main thread's destructor
     // runs at process exit only, possibly from a signal path with a HIP call on the stack: leave
@@ -116,6 +141,47 @@ extern "C" int amt_host_release(void)
 {
     tl_workspace.release();
     return AMT_OK;
+}
+
+extern "C" int amt_host_cache_enable(int on)
+{
+    HostWorkspace &ws = tl_workspace;
+    if (!on && ws.res.enabled && ws.device >= 0) {
+        DeviceScope dev(ws.device);
+        for (hipStream_t st : {ws.up, ws.comp, ws.down})
+            if (st) (void)hipStreamSynchronize(st);
+        ws.res.drop();
+    }
+    ws.res.enabled = on != 0;
+    return AMT_OK;
+}
+
+extern "C" int amt_host_cache_check(int on)
+{
+    tl_workspace.res.check = on != 0;
+    return AMT_OK;
+}
+
+extern "C" int amt_host_invalidate(const void *host_ptr)
+{
+    HostWorkspace::Resident &r = tl_workspace.res;
+    int hit = 0;
+    for (int q = 0; q < HostWorkspace::NRES; ++q)
+        if (!host_ptr || r.host[q] == host_ptr) { r.valid[q] = false; ++hit; }
+    (void)hit;                                                // an array that is not cached is uploaded anyway
+    return AMT_OK;
+}
+
+// 64-bit checksum of a host array's rows (check mode only: it reads the whole array)
+static uint64_t amt_host_sum(const void *p, size_t bytes)
+{
+    const uint64_t *w = static_cast<const uint64_t *>(p);
+    const size_t n = bytes / 8;
+    uint64_t a = 0x9e3779b97f4a7c15ull, b = 0;
+    for (size_t i = 0; i < n; ++i) { a = (a ^ w[i]) * 0x100000001b3ull; b += w[i] + (a >> 29); }
+    const unsigned char *tail = static_cast<const unsigned char *>(p) + n * 8;
+    for (size_t i = 0; i < bytes % 8; ++i) a = (a ^ tail[i]) * 0x100000001b3ull;
+    return a ^ (b << 1);
 }
 
 // One-shot call = upload, kernel, download.  Three regimes, chosen per call:
@@ -250,6 +316,50 @@ static int amt_host_call(const AmtArgs<T> &h)
         }
     }
     const size_t arena_end = ws.used;
+
+    // ---- residency cache: whole-window copies of ww_1, u_1, v_1, t_1, ft ----------------------------------
+    static const int res_field[HostWorkspace::NRES] = {1, 3, 5, 14, 16};
+    int res_of[26];
+    for (int f = 0; f < 26; ++f) res_of[f] = -1;
+    HostWorkspace::Resident &res = ws.res;
+    bool res_upload[HostWorkspace::NRES] = {};
+    if (res.enabled) {
+        const int key[16] = {(int)sizeof(T), h.ims, h.ime, h.kms, h.kme, h.jms, h.jme, w.j_start, w.j_end, p.i0, p.i1, p.nk, device, 0, 0, 0};
+        const size_t each = r3 * wrow * sizeof(T);
+        bool same = res.bytes_each == each && memcmp(res.key, key, sizeof key) == 0;
+        for (int r = 0; r < HostWorkspace::NRES && same; ++r) same = res.host[r] == items[res_field[r]].host;
+        if (!same) {
+            // another patch, another layout or other arrays: start over (nothing is in flight between calls)
+            res.drop();
+            for (int r = 0; r < HostWorkspace::NRES; ++r) {
+                const hipError_t e = hipMalloc((void **)&res.buf[r], each);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    res.drop();
+                    return amt_fail(AMT_ERR_ALLOC, "residency cache: hipMalloc of %zu bytes failed (amt_host_cache_enable(0) runs without it)", each);
+                }
+                res.host[r] = items[res_field[r]].host;
+            }
+            res.bytes_each = each;
+            memcpy(res.key, key, sizeof key);
+        }
+        for (int r = 0; r < HostWorkspace::NRES; ++r) {
+            res_of[res_field[r]] = r;
+            res_upload[r] = !res.valid[r];
+            if (res.check) {
+                // debug mode: a cached array that changed on the host without amt_host_invalidate is an error
+                const T *rows0 = items[res_field[r]].host + (size_t)(w.j_start - 1 - h.jms) * r3;
+                const uint64_t now_sum = amt_host_sum(rows0, each);
+                if (res.valid[r] && now_sum != res.sum[r]) {
+                    static const char *names[HostWorkspace::NRES] = {"ww_1", "u_1", "v_1", "t_1", "ft"};
+                    res.valid[r] = false;
+                    return amt_fail(AMT_ERR_PRECONDITION, "residency cache: %s changed on the host since it was uploaded "
+                                    "but amt_host_invalidate was not called for it (amt_host_cache_check)", names[r]);
+                }
+                res.sum[r] = now_sum;
+            }
+        }
+    }
     // staging buffer: mirrors the arena from stage_base on
     const size_t stage_base = pack_big ? 0 : small_begin;
     char *stage = nullptr;
@@ -372,6 +482,12 @@ static int amt_host_call(const AmtArgs<T> &h)
             }
             const int lo = it.halo ? c0 - 1 : c0, hi = it.halo ? c1 + 1 : c1;
             const size_t n = (size_t)(hi - lo + 1) * r3 * sizeof(T);
+            if (res_of[f] >= 0) {                             // resident: its rows go up only while it is stale
+                if (res_upload[res_of[f]])
+                    AMT_HIP(hipMemcpyAsync(reinterpret_cast<T *>(res.buf[res_of[f]]) + (size_t)(lo - (w.j_start - 1)) * r3,
+                                           it.host + (size_t)(lo - h.jms) * r3, n, hipMemcpyHostToDevice, up));
+                continue;
+            }
             if (pack_big) memcpy(staged(dev[s][f]) + (size_t)(lo - ja) * r3, it.host + (size_t)(lo - h.jms) * r3, n);
             else AMT_HIP(hipMemcpyAsync(dev[s][f] + (size_t)(lo - ja) * r3, it.host + (size_t)(lo - h.jms) * r3, n,
                                         hipMemcpyHostToDevice, up));
@@ -382,7 +498,8 @@ static int amt_host_call(const AmtArgs<T> &h)
         AmtArgs<T> d = h;
         T *q[26];
         for (int f = 0; f < 26; ++f)                          // every array as if it began at row ja
-            q[f] = items[f].rank == 2 ? dev[0][f] + (size_t)(ja - (w.j_start - 1)) * r2 : dev[s][f];
+            q[f] = items[f].rank == 2 ? dev[0][f] + (size_t)(ja - (w.j_start - 1)) * r2
+                 : res_of[f] >= 0 ? reinterpret_cast<T *>(res.buf[res_of[f]]) + (size_t)(ja - (w.j_start - 1)) * r3 : dev[s][f];
         d.ww = q[0]; d.ww_1 = q[1]; d.u = q[2]; d.u_1 = q[3]; d.v = q[4]; d.v_1 = q[5]; d.mu = q[6];
         d.mut = q[7]; d.muave = q[8]; d.muts = q[9]; d.muu = q[10]; d.muv = q[11]; d.mudf = q[12];
         d.t = q[13]; d.t_1 = q[14]; d.t_ave = q[15]; d.ft = q[16]; d.mu_tend = q[17];
@@ -450,6 +567,8 @@ static int amt_host_call(const AmtArgs<T> &h)
         if (e != hipSuccess && rc == AMT_OK)
             rc = amt_fail(AMT_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
     }
+    if (res.enabled)
+        for (int r = 0; r < HostWorkspace::NRES; ++r) res.valid[r] = (rc == AMT_OK);
     if (trace)
         fprintf(stderr, "amt one-shot: %d chunk(s) of %ld rows, 3-D %s%s, small arrays %s; alloc %.2f ms, enqueue %.2f ms, drain %.2f ms\n",
                 nchunk, rows, pinned ? "pinned" : pack_big ? "packed" : "pageable", threaded ? " + download thread" : "",

@@ -74,6 +74,9 @@ SYMBOLS = {
     "amt_host_pin": (_I, [_P, ctypes.c_size_t]),
     "amt_host_unpin": (_I, [_P]),
     "amt_host_release": (_I, []),
+    "amt_host_cache_enable": (_I, [_I]),
+    "amt_host_cache_check": (_I, [_I]),
+    "amt_host_invalidate": (_I, [_P]),
     "amt_set_device": (_I, [_I]),
     "amt_comm_unique_id": (_I, [_P]),
     "amt_comm_rendezvous_file": (_I, [ctypes.c_char_p, ctypes.c_uint64, _I, _I, ctypes.c_double, _P]),
