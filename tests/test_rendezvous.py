@@ -70,3 +70,36 @@ def test_bad_arguments(pkg, tmp_path):
     assert L.amt_comm_rendezvous_file(p, 1, -1, 2, 0.1, out) == lib.ERR_INVALID_ARG
     assert L.amt_comm_rendezvous_file(b"", 1, 1, 2, 0.1, out) == lib.ERR_INVALID_ARG
     assert L.amt_comm_rendezvous_file(p, 1, 1, 2, 0.1, None) == lib.ERR_INVALID_ARG
+
+
+def test_ranks_of_one_scheduler_job_agree_without_a_common_parent(pkg):
+    """per-node srun / orted daemons give the ranks of one job DIFFERENT parents; the job id the
+    scheduler exports must then decide the nonce, not the parent process.  Two child processes started through
+    two different intermediate shells (different ppid) with the same SLURM_JOB_ID compute the same value; with
+    different job ids, or with neither job id nor a common parent, different ones."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as g; "
+            "print(g.load_package().load_library().amt_comm_launch_nonce())" % str(root))
+
+    def via_own_shell(extra):
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("AMT_RENDEZVOUS_NONCE", "SLURM_JOB_ID", "SLURM_STEP_ID", "PMI_JOBID", "PMIX_NAMESPACE",
+                            "TORCHELASTIC_RUN_ID", "LSB_JOBID", "PBS_JOBID", "PMI_ID_JOB", "OMPI_MCA_ess_base_jobid")}
+        env.update(extra)
+        # `sh -c '...; true'` keeps the shell alive as the python process's parent: one parent per rank
+        r = subprocess.run(["sh", "-c", f"{sys.executable} -c \"{code}\"; true"], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-500:]
+        return int(r.stdout.strip().splitlines()[-1])
+
+    job = {"SLURM_JOB_ID": "4711", "SLURM_STEP_ID": "0", "MASTER_PORT": "29500"}
+    a, b = via_own_shell(job), via_own_shell(job)
+    assert a == b and a != 0
+    assert via_own_shell(dict(job, SLURM_JOB_ID="4712")) != a
+    c, d = via_own_shell({"MASTER_PORT": "29500"}), via_own_shell({"MASTER_PORT": "29500"})
+    assert c != d                                  # hand-started ranks: no common parent, no job id -> need AMT_RENDEZVOUS_NONCE
+    e, f = via_own_shell({"AMT_RENDEZVOUS_NONCE": "x"}), via_own_shell({"AMT_RENDEZVOUS_NONCE": "x"})
+    assert e == f

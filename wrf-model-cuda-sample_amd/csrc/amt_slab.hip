@@ -113,14 +113,26 @@ uint64_t amt_fnv1a(uint64_t h, const void *data, size_t n)
 }  // namespace
 
 // A value every process of ONE launch computes identically and two launches do not share:
-// AMT_RENDEZVOUS_NONCE if set; else the launcher's run id (TORCHELASTIC_RUN_ID + restart count);
-// else the parent process (pid and start time from /proc: the ranks of a launch are children
-// of one launcher) together with MASTER_PORT.  Never 0.
+// AMT_RENDEZVOUS_NONCE if set; else a job id the scheduler gives every rank of the job (SLURM_JOB_ID +
+// step, PMI / PMIx / Open MPI job ids, LSB_JOBID, PBS_JOBID) -- such ranks need not share a parent
+// process (one srun / orted daemon per node); else the launcher's run id (TORCHELASTIC_RUN_ID + restart
+// count) and the parent process (pid and start time from /proc: the ranks of a local launch are children of
+// one launcher) together with MASTER_PORT.  Ranks started by hand (a shell or ssh per rank) have neither a job
+// id nor a common parent: they must be given AMT_RENDEZVOUS_NONCE.  Never 0.
 extern "C" uint64_t amt_comm_launch_nonce(void)
 {
     uint64_t h = 1469598103934665603ull;
+    static const char *const job_ids[] = {"SLURM_JOB_ID", "SLURM_STEP_ID", "PMI_JOBID", "PMI_ID_JOB", "PMIX_NAMESPACE",
+                                          "OMPI_MCA_ess_base_jobid", "LSB_JOBID", "PBS_JOBID"};
+    bool have_job = false;
+    for (const char *name : job_ids)
+        if (const char *t = getenv(name); t && *t) have_job = true;
     if (const char *s = getenv("AMT_RENDEZVOUS_NONCE"); s && *s) {
         h = amt_fnv1a(h, s, strlen(s));
+    } else if (have_job) {
+        for (const char *name : job_ids)
+            if (const char *t = getenv(name); t && *t) { h = amt_fnv1a(h, name, strlen(name)); h = amt_fnv1a(h, t, strlen(t)); }
+        if (const char *t = getenv("MASTER_PORT"); t && *t) h = amt_fnv1a(h, t, strlen(t));
     } else {
         // the launcher's run id alone may be a fixed word ("none" for a static rendezvous): always
         // mix in the parent process as well
@@ -218,7 +230,8 @@ extern "C" int amt_comm_rendezvous_file(const char *path, uint64_t nonce, int ra
             }
         }
         if (waited() > timeout_s)
-            return amt_fail(AMT_ERR_COMM, saw_stale ? "%s belongs to another launch (nonce mismatch) after %.0f s"
+            return amt_fail(AMT_ERR_COMM, saw_stale ? "%s belongs to another launch (nonce mismatch) after %.0f s; ranks that do not share "
+                                                      "a parent process or a scheduler job id need the same AMT_RENDEZVOUS_NONCE"
                                                     : "no rendezvous file %s after %.0f s", path, timeout_s);
         std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
@@ -354,6 +367,21 @@ int amt_slab_step_t(amt_slab *s, int n_sweeps)
     amt_domain *d = s->dom;
     const int jlo = d->jts, jhi = d->jte;
     const bool lo = s->below >= 0, hi = s->above >= 0;
+    // the rows the routine really updates in this slab (module_small_step_em.f90:91-106): with specified /
+    // nested boundaries the first / last row of an outermost slab is clipped away.  The one-launch edge path
+    // computes rows j_start and j_end of the CLIPPED window, so it is only right when nothing is clipped
+    // (always, for a slab with a neighbour on that side -- except in loopback, where the rank is its own
+    // neighbour on a slab that touches the domain edge).
+    const AmtWindow wclip = amt_window(d->periodic_x, d->specified, d->nested, d->ids, d->ide, d->jds, d->jde,
+                                       d->its, d->ite, jlo, jhi, d->kts, d->kte);
+    const bool unclipped = wclip.j_start == jlo && wclip.j_end == jhi;
+    // a failure between the fork (inputs_final) and the join (edges_done) must not leave the streams apart
+    auto join = [&]() {
+        if (s->overlap) {
+            (void)hipEventRecord(s->edges_done, s->comm_stream);
+            (void)hipStreamWaitEvent(d->stream, s->edges_done, 0);
+        }
+    };
     for (int sweep = 0; sweep < n_sweeps; ++sweep) {
         int rc = AMT_OK;
         if (!lo && !hi) {
@@ -368,23 +396,23 @@ int amt_slab_step_t(amt_slab *s, int n_sweeps)
             AMT_HIP(hipEventRecord(s->inputs_final, d->stream));          // this sub-step's inputs are final
             AMT_HIP(hipStreamWaitEvent(s->comm_stream, s->inputs_final, 0));
             rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi);              // interior overlaps the exchange
-            if (rc) return rc;
+            if (rc) { join(); return rc; }
         }
         rc = amt_slab_enqueue_exchange(s, edge_stream);
-        if (rc) return rc;
+        if (rc) { join(); return rc; }
         if (!s->overlap) {
             rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi);
             if (rc) return rc;
         }
-        if (lo && hi && jhi > jlo) {                                        // both boundary rows in one launch
+        if (lo && hi && jhi > jlo && unclipped) {                           // both boundary rows in one launch
             AmtArgs<T> a;
             amt_domain_args<T>(d, a);
             a.jts = jlo; a.jte = jhi;
             rc = amt_device_call_edges<T>(edge_stream, d->variant, a);
-            if (rc) return rc;
-        } else {
-            if (lo) { rc = amt_slab_tile<T>(s, edge_stream, jlo, jlo < jhi ? jlo : jhi); if (rc) return rc; }
-            if (hi && (jhi > jlo || !lo)) { rc = amt_slab_tile<T>(s, edge_stream, jhi, jhi); if (rc) return rc; }
+            if (rc) { join(); return rc; }
+        } else {                                                            // two one-row tiles, each clipped on its own
+            if (lo) { rc = amt_slab_tile<T>(s, edge_stream, jlo, jlo < jhi ? jlo : jhi); if (rc) { join(); return rc; } }
+            if (hi && (jhi > jlo || !lo)) { rc = amt_slab_tile<T>(s, edge_stream, jhi, jhi); if (rc) { join(); return rc; } }
         }
         if (s->overlap) {
             AMT_HIP(hipEventRecord(s->edges_done, s->comm_stream));
