@@ -88,3 +88,43 @@ def test_slab_driver_loopback_agrees_with_the_torch_path(pkg, drivers, tmp_path,
     mu = want.to_host().arrays["mu"]
     total = mu[1:-1, 1 - b.ims:1 - b.ims + ni].astype(np.float64).sum()
     assert abs(float(m.group(2)) - total) <= 1e-9 * abs(total), (m.group(2), total)
+
+
+@pytest.mark.gpu
+def test_two_fortran_ranks_on_one_device_rendezvous_then_fail_cleanly(pkg, drivers, tmp_path):
+    """Two processes of advance_mu_t_slab_driver (WORLD_SIZE = 2) with no launcher and no MPI: the communicator
+    id travels through the nonce-bound rendezvous file (started from two different parent shells, so the nonce
+    comes from AMT_RENDEZVOUS_NONCE), both reach ncclCommInitRank -- and on a one-GPU box RCCL refuses two
+    ranks on one device ("invalid usage").  Both must then stop with the library's message and a non-zero
+    status, promptly, and leave no rendezvous file behind.  Where two devices are visible the same launch
+    simply has to succeed."""
+    import os
+    import time
+    exe = FDIR / "advance_mu_t_slab_driver_f64"
+    ndev = pkg.load_library().amt_device_count()
+    uid = tmp_path / "uid"
+    procs = []
+    t0 = time.time()
+    for rank in (0, 1):
+        env = dict(os.environ, AMT_RENDEZVOUS_FILE=str(uid), AMT_RENDEZVOUS_NONCE="fortran-pair-1", RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK=str(rank if ndev >= 2 else 0), MASTER_PORT="29555", NCCL_DEBUG="WARN")
+        procs.append(subprocess.Popen(["sh", "-c", f"{exe} 256 20 64 2; echo EXIT $?"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a Fortran rank hung: " + "".join(outs))
+    took = time.time() - t0
+    codes = [int(o.strip().splitlines()[-1].split()[-1]) for o in outs]
+    if ndev >= 2:
+        assert codes == [0, 0], outs
+        assert "ranks seen" in outs[0] or "sum(mu)" in outs[0], outs[0]
+    else:
+        assert all(c != 0 for c in codes), outs
+        assert all("amt:" in o and ("ncclCommInitRank" in o or "RCCL" in o) for o in outs), outs
+        assert took < 200, took
+    assert not uid.exists() and not list(tmp_path.glob("uid.ack.*")), "the rendezvous leaves nothing behind"

@@ -10,7 +10,8 @@ from conftest import bits_equal
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = int(os.environ.get("AMT_RANDOM_CASES", "40"))
+N_CASES = int(os.environ.get("AMT_RANDOM_CASES", "400"))
+SEED = int(os.environ.get("AMT_RANDOM_SEED", "20261002"))
 
 
 def random_case(pkg, rng):
@@ -46,9 +47,13 @@ def random_case(pkg, rng):
 def test_random_cases_match_oracle(pkg, oracle):
     import torch
     torch.cuda.set_device(0)
-    rng = np.random.default_rng(20261002)
+    import json
+    import time
+    from pathlib import Path
+    rng = np.random.default_rng(SEED)
     S = pkg.synth
-    ran = {"march": 0, "column": 0, "oneshot": 0}
+    ran = {"march": 0, "column": 0, "oneshot": 0, "oneshot_cached": 0}
+    t_start = time.time()
     L = pkg.load_library()
     for case in range(N_CASES):
         b, cfg, dtype, dims = random_case(pkg, rng)
@@ -77,5 +82,27 @@ def test_random_cases_match_oracle(pkg, oracle):
             for n in S.FIELD_NAMES:
                 assert bits_equal(one.arrays[n], want.arrays[n]), f"{what}: one-shot, {n} differs"
             ran["oneshot"] += 1
+        if case % 16 == 8:
+            # the one-shot call with the residency cache: two sub-steps, the second one without re-uploading
+            # ww_1, u_1, v_1, t_1, ft (checksum mode on: a stale cached array would be refused)
+            one, two = host.copy(), want.copy()
+            pkg.host_cache_enable(True, check=True)
+            try:
+                pkg.advance_mu_t(*one.args())
+                pkg.advance_mu_t(*one.args())
+            finally:
+                pkg.host_cache_enable(False)
+            oracle.advance_mu_t(*two.args())
+            for n in S.FIELD_NAMES:
+                assert bits_equal(one.arrays[n], two.arrays[n]), f"{what}: cached one-shot, second sub-step, {n} differs"
+            ran["oneshot_cached"] += 1
     L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
+    summary = {"seed": SEED, "cases": N_CASES, "wall_s": round(time.time() - t_start, 1), "ran": ran, "failures": 0,
+               "what": "tests/test_gpu_random.py: random extents (to 700 columns, 300 levels), paddings, sub-tiles, flags, "
+                       "precisions; march (LDS-DMA / register flavour) and column kernels, one-shot, cached one-shot; "
+                       "bit-exact against the oracle"}
+    print("random campaign:", json.dumps(summary))
+    out = Path(__file__).resolve().parent.parent / "gpurun_out"
+    if out.is_dir():
+        (out / f"random_campaign_{N_CASES}.json").write_text(json.dumps(summary, indent=1) + "\n")
     assert ran["march"] >= N_CASES * 0.8 and ran["column"] >= N_CASES * 0.95
