@@ -74,7 +74,7 @@ def test_torch_stepper_with_two_real_ranks():
 
 
 def test_single_gpu_line_carries_the_contract_keys():
-    out = _run(["--ni", "256", "--nj", "256", "--steps", "3", "--warmup", "2", "--cpu-seconds", "1", "--cpu-rows", "8"])
+    out = _run(["--ni", "256", "--nj", "256", "--steps", "3", "--warmup", "2", "--cpu-seconds", "8", "--cpu-rows", "16"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "verified_vs_oracle"):
         assert key in out, key
@@ -86,7 +86,7 @@ def test_single_gpu_line_carries_the_contract_keys():
     # the CPU baseline is the Fortran CPU path, one child process per entry
     cb = out["cpu_baseline"]
     assert cb["impl"].startswith("fortran") and cb["value"] and cb["value"] > 0
-    assert any(m["impl"] == "fortran" and m["threads"] == 1 for m in cb["matrix"])
+    assert any(m["impl"] == "fortran" for m in cb["matrix"]) and cb["leg_seconds"] < 60
     # attribution: this box's own streaming rates and what they make of the launch
     for key in ("box_copy_GBps", "box_read_GBps", "box_mixed_ceiling_ms", "frac_of_box_copy", "frac_of_box_mixed"):
         assert key in rf and rf[key] > 0, key

@@ -60,6 +60,24 @@ MODULE amt_c_binding
          import :: c_int
          integer(c_int) :: rc
       end function
+      ! residency cache of the one-shot calls of this thread: ww_1, u_1, v_1, t_1, ft stay on the device
+      ! between calls (the sub-steps of one Runge-Kutta stage) and go up again only after amt_host_invalidate
+      ! (c_null_ptr: all of them -- a new stage); amt_host_cache_check(1): checksum debug mode
+      function amt_host_cache_enable(on) bind(C, name="amt_host_cache_enable") result(rc)
+         import :: c_int
+         integer(c_int), value :: on
+         integer(c_int) :: rc
+      end function
+      function amt_host_cache_check(on) bind(C, name="amt_host_cache_check") result(rc)
+         import :: c_int
+         integer(c_int), value :: on
+         integer(c_int) :: rc
+      end function
+      function amt_host_invalidate(ptr) bind(C, name="amt_host_invalidate") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: ptr
+         integer(c_int) :: rc
+      end function
 
       ! error text of the calling thread (NUL-terminated C string)
       function amt_last_error() bind(C, name="amt_last_error") result(msg)
