@@ -58,6 +58,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -1013,7 +1014,7 @@ static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 0};
 static thread_local char g_march_last[360] = "";
 extern "C" const char *amt_march_last_kernel(void) { return g_march_last; }
 void amt_march_note_kernel(const char *name) { snprintf(g_march_last, sizeof g_march_last, "%s", name); }   // amt_api.hip: column kernel
-static int g_march_generation = 0;                 // bumped by amt_march_force_shape: cached plans are stale
+static std::atomic<int> g_march_generation{0};     // bumped by amt_march_force_shape: cached plans are stale (host threads plan concurrently)
 static std::once_flag g_march_env_once;
 static const AmtMarchEnv &amt_march_env()
 {
@@ -1287,12 +1288,17 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
             }
         }
     }
-    if (pl.lds > 64 * 1024 && !(pl.entry->lds_granted[pl.full] >> (pl.dev & 31) & 1u)) {
+    if (pl.lds > 64 * 1024) {
         // the attribute is per device and per kernel instantiation: allow all of the CU's LDS once
-        // (what a launch occupies is its own dynamic size, not this ceiling)
-        hipError_t e = hipFuncSetAttribute(pl.entry->kernel[pl.full], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-        pl.entry->lds_granted[pl.full] |= 1u << (pl.dev & 31);
+        // (what a launch occupies is its own dynamic size, not this ceiling); one-shot calls plan from
+        // several host threads at once
+        static std::mutex grant;
+        std::lock_guard<std::mutex> lk(grant);
+        if (!(pl.entry->lds_granted[pl.full] >> (pl.dev & 31) & 1u)) {
+            hipError_t e = hipFuncSetAttribute(pl.entry->kernel[pl.full], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+            pl.entry->lds_granted[pl.full] |= 1u << (pl.dev & 31);
+        }
     }
     char sched[200] = "";
     if (g.nseg) {
