@@ -10,7 +10,7 @@ from conftest import bits_equal
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = int(os.environ.get("AMT_RANDOM_CASES", "400"))
+N_CASES = int(os.environ.get("AMT_RANDOM_CASES", "2000"))
 SEED = int(os.environ.get("AMT_RANDOM_SEED", "20261002"))
 
 
