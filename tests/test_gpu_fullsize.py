@@ -150,3 +150,68 @@ def test_streamed_one_shot_on_a_many_chunk_domain(pkg, oracle, pinned):
         assert bits_equal(host.arrays[n], want.arrays[n]), n
     print(f"  one-shot call: {dt:.2f} s = {np.prod(dims) / dt / 1e9:.2f} Gcells/s, {gb:.0f} GB of host arrays")
     assert dt < 60 * max(1.0, gb / 13.6), dt
+
+
+def test_configs4_at_its_stated_size_through_the_streamed_host_path(pkg, oracle):
+    """BASELINE.json configs[4] names "8192 x 80 x 8192 fp32 ... async H2D/D2H": the one-shot host drop-in on the
+    whole 219 GB of host arrays (reference precedent: advance_mu_t_no_async.cu:245-306, 366-390 with the pinned
+    host buffers of advance_mu_t_driver.cu:97-167).  The host cannot hold a second copy for the oracle, so the
+    result is checked the way the resident full-size tests are: 16-row j chunks -- both domain edges and chunks
+    that straddle the call's chunk seams -- recomputed by the oracle from regenerated inputs (the generator is
+    index-based), bit for bit, every output array.  Needs ~245 GB of host memory the process may really use
+    (MemAvailable capped by the cgroup); skipped with that figure otherwise."""
+    import torch
+    S = pkg.synth
+    L = pkg.load_library()
+    dims = (8192, 80, 8192)
+    if os.environ.get("AMT_STREAM_TEST_DIMS"):
+        dims = tuple(int(x) for x in os.environ["AMT_STREAM_TEST_DIMS"].split("x"))
+    b = S.domain_bounds(*dims)
+    gb = 10.3 * b.idim * b.kdim * b.jdim * 4 / 1e9
+    host_gb = _host_gb()
+    if 1.1 * gb + 4 > 0.8 * host_gb:
+        pytest.skip(f"needs {(1.1 * gb + 4) / 0.8:.0f} GB of host memory (have {host_gb:.0f}); "
+                    f"test_streamed_one_shot_on_a_many_chunk_domain covers the largest size that fits")
+    if torch.cuda.mem_get_info(0)[0] < 40e9:
+        pytest.skip("needs 40 GB of free HBM for the generator's staging array and the call's workspace")
+    cfg = pkg.GridConfig(specified=True)
+    seed = 77
+    t_gen = time.time()
+    arrays = {}
+    for name in S.FIELD_NAMES:                                  # one array at a time through the device generator
+        t = torch.empty(b.shape(name), dtype=torch.float32, device="cuda:0")
+        fa, _ = S._fill_args(b, name, dims)
+        pkg.lib.check(L.amt_synth_fill_device(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), S.FIELD_ID[name], 4,
+                                              ctypes.c_void_p(t.data_ptr()), ctypes.c_uint64(seed), *fa))
+        arrays[name] = t.cpu().numpy()
+        del t
+        torch.cuda.empty_cache()
+    host = S.Patch(b, cfg, arrays, global_dims=dims)
+    print(f"configs[4] streamed: {gb:.0f} GB of host arrays generated in {time.time() - t_gen:.0f} s, host memory available {host_gb:.0f} GB")
+    rows_per_chunk = int((320 << 20) / (b.idim * b.kdim * 4 * 10) + 1)       # the call's own chunking (amt_oneshot.hip)
+    t0 = time.time()
+    try:
+        pkg.advance_mu_t(*host.args())
+    finally:
+        L.amt_host_release()
+    dt = time.time() - t0
+    print(f"  one-shot call (pageable arrays, download thread): {dt:.2f} s = {np.prod(dims) / dt / 1e9:.2f} Gcells/s, "
+          f"{rows_per_chunk} rows per chunk, {-(-dims[2] // rows_per_chunk)} chunks")
+    rows = 16
+    first = 2                                                    # specified: j_start = jds + 1
+    nchunk = -(-(dims[2] - 2) // rows_per_chunk)
+    seams = [first + rows_per_chunk * k for k in sorted({1, nchunk // 5, nchunk // 2, (4 * nchunk) // 5, nchunk - 1})]
+    starts = [1, dims[2] - rows + 1] + [x - rows // 2 for x in seams if rows // 2 < x and x + rows // 2 <= dims[2]]
+    threads = _granted_cores(rows)
+    for jlo in starts:
+        jhi = jlo + rows - 1
+        sb = b.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
+        want = S.make_patch(sb, cfg, dtype=np.float32, seed=seed, global_dims=dims, device="cuda:0").to_host()
+        oracle.advance_mu_t_omp(*want.args(), nthreads=threads)
+        for n in S.OUTPUTS:
+            got = host.arrays[n][jlo - b.jms: jhi + 1 - b.jms]
+            assert bits_equal(np.ascontiguousarray(got), want.arrays[n][1:-1]), f"rows {jlo}..{jhi}: {n} differs from the oracle"
+    # nothing outside the window was written: row jds and row jde-1 .. jde of an output still hold the generator's values
+    edge = S.make_patch(b.replace(jms=0, jme=2, jts=1, jte=1), cfg, dtype=np.float32, seed=seed, global_dims=dims, device="cuda:0").to_host()
+    assert bits_equal(np.ascontiguousarray(host.arrays["t"][0:2]), edge.arrays["t"][0:2])
+    assert dt < 120, dt
