@@ -102,7 +102,22 @@ for k in range(a.placements):
     dev = S.make_patch(b, pkg.GridConfig(), dtype=dtype, seed=1, device="cuda:0")
     lo, hi = timed(pkg.bind_device_call(*dev.args()))
     bases = {n: dev.arrays[n].data_ptr() for n in S.RANK3}
+    # does a plain read-only stream over the SAME pages see the placement too?  (then it is the memory side,
+    # not this kernel's access pattern)
+    sink = torch.zeros(8, dtype=torch.float64, device="cuda")
+    stream_rates = {}
+    for n in ("u", "t_1", "ft", "ww_1"):
+        t = dev.arrays[n]
+        nb = t.numel() * t.element_size() // 16 * 16
+        s_ = torch.cuda.current_stream().cuda_stream
+
+        def rd(t=t, nb=nb):
+            assert L.amt_calib_stream_rate(ctypes.c_void_p(s_), ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(t.data_ptr()),
+                                           ctypes.c_size_t(nb), 1) == 0
+        rlo, _ = timed(rd, reps=4, rounds=2)
+        stream_rates[n] = round(nb / rlo / 1e6, 1)
     place.append({"placement": k, "ms_min": round(lo, 3), "ms_max": round(hi, 3), "frac": round(abytes / lo / 1e6 / 8000, 4),
+                  "read_stream_GBps": stream_rates,
                   "base_mod_2MiB": {n: p % (1 << 21) for n, p in bases.items()},
                   "base_GiB": {n: round(p / 2**30, 3) for n, p in bases.items()}})
     print(json.dumps(place[-1]), flush=True)
