@@ -145,10 +145,6 @@ int amt_host_release(void);
  * and level 1 of ww, which change from sub-step to sub-step, the 2-D and 1-D arrays (1/NK of the data) and all
  * outputs cross the link on every call as before.  The reference re-uploads everything on every call
  * (advance_mu_t_no_async.cu:245-306).
- * amt_host_cache_enable(2) additionally keeps the in/out state t on the device: the routine's own update is then
- * taken to be the only change of t between two calls (true inside the acoustic loop: advance_uv and advance_w do
- * not write t); after anything else has written the host t, amt_host_invalidate(t).  t still comes DOWN on every
- * call -- only its upload is saved.  (Not in the packed regime of small pageable patches, which runs as mode 1.)
  * amt_host_cache_check(1) is the debug mode: every call checksums the cached arrays on the host and fails with
  * AMT_ERR_PRECONDITION if one changed without an invalidate (it reads the whole arrays: slow).
  * amt_host_cache_enable(0) and amt_host_release() free the copies. */

@@ -119,13 +119,6 @@ def main():
                                                                     if n not in ("ww_1", "u_1", "v_1", "t_1", "ft", "t_ave", "ww")) / 1e9, 3)}
         finally:
             pkg.host_cache_enable(False)
-        pkg.host_cache_enable(True, state=True)                 # mode 2: t stays resident too
-        try:
-            pkg.advance_mu_t(*p.args())
-            t = run(p)
-            out["pinned_cached_state"] = {"later_calls_ms": round(t * 1e3, 2), "Mcells_per_s": round(cells / t / 1e6, 1)}
-        finally:
-            pkg.host_cache_enable(False)
     finally:
         for arr in pinned:
             lib.check(L.amt_host_unpin(arr.ctypes.data_as(ctypes.c_void_p)))

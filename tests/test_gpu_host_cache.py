@@ -116,69 +116,3 @@ def test_cache_off_is_the_default_and_the_key_follows_the_arrays(pkg, oracle):
     finally:
         pkg.host_cache_enable(False)
         pkg.load_library().amt_host_release()
-
-
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("rows,pin", [(None, False), (9, False), (9, True)])
-def test_mode_2_keeps_t_resident_over_the_sub_steps(pkg, oracle, monkeypatch, dtype, rows, pin):
-    """amt_host_cache_enable(2): t is uploaded by the first call only; the kernel updates the resident copy in
-    place and every call downloads it.  Big enough (or forced into chunks) not to take the packed regime.  Then the
-    host rewrites t: refused without an invalidate (checksum mode), used after it."""
-    import ctypes
-    L = pkg.load_library()
-    if rows:
-        monkeypatch.setenv("AMT_STREAM_ROWS", str(rows))
-    b = pkg.synth.domain_bounds(600, 40, 64) if rows is None else pkg.synth.domain_bounds(200, 30, 40)
-    got = pkg.synth.make_patch(b, pkg.GridConfig(specified=True), dtype=dtype, seed=21)
-    want = got.copy()
-    pins = []
-    pkg.host_cache_enable(True, check=True, state=True)
-    try:
-        if pin:
-            for n in pkg.synth.RANK3:
-                a = got.arrays[n]
-                pkg.lib.check(L.amt_host_pin(a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
-                pins.append(a)
-        rng = np.random.default_rng(9)
-        for step in range(4):
-            if step:
-                state = rng.bit_generator.state
-                _perturb(got, rng, ("u", "v"))
-                rng.bit_generator.state = state
-                _perturb(want, rng, ("u", "v"))
-            pkg.advance_mu_t(*got.args())
-            oracle.advance_mu_t(*want.args())
-            assert_patch_equal(pkg, got, want, f"mode 2 sub-step {step}")
-        for p in (got, want):
-            p.arrays["t"] += 1.0                                  # something else writes theta
-        with pytest.raises(pkg.AmtError) as err:
-            pkg.advance_mu_t(*got.args())
-        assert " t changed on the host" in str(err.value)
-        pkg.host_invalidate(got.arrays["t"])
-        pkg.advance_mu_t(*got.args())
-        oracle.advance_mu_t(*want.args())
-        assert_patch_equal(pkg, got, want, "mode 2 after the invalidate")
-    finally:
-        for a in pins:
-            L.amt_host_unpin(a.ctypes.data_as(ctypes.c_void_p))
-        pkg.host_cache_enable(False)
-        L.amt_host_release()
-
-
-def test_mode_2_on_a_small_pageable_patch_runs_as_mode_1(pkg, oracle):
-    """The packed regime (small, pageable, one chunk) brings its outputs back as one image of the device arena, where a
-    resident t is not: there mode 2 keeps only the constants resident -- and stays right."""
-    pkg.host_cache_enable(True, check=True, state=True)
-    try:
-        b = pkg.synth.domain_bounds(48, 10, 12)
-        got = pkg.synth.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=4)
-        want = got.copy()
-        for step in range(3):
-            for p in (got, want):
-                p.arrays["t"] += 0.5                              # allowed here: t is uploaded every call
-            pkg.advance_mu_t(*got.args())
-            oracle.advance_mu_t(*want.args())
-            assert_patch_equal(pkg, got, want, f"packed sub-step {step}")
-    finally:
-        pkg.host_cache_enable(False)
-        pkg.load_library().amt_host_release()

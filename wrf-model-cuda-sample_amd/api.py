@@ -140,12 +140,11 @@ def advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf,
 advance_mu_t.bind = bind_device_call        # SlabStepper pre-marshals its per-sweep launches through this
 
 
-def host_cache_enable(on: bool = True, check: bool = False, state: bool = False) -> None:
+def host_cache_enable(on: bool = True, check: bool = False) -> None:
     """Residency cache of the one-shot (numpy) calls of the calling thread: ww_1, u_1, v_1, t_1, ft stay on the
-    device between calls (header section 1: amt_host_cache_enable); ``state``: the in/out t as well (mode 2).
-    ``check``: the checksum debug mode."""
+    device between calls (header section 1: amt_host_cache_enable).  ``check``: the checksum debug mode."""
     L = _lib.load_library()
-    _lib.check(L.amt_host_cache_enable((2 if state else 1) if on else 0))
+    _lib.check(L.amt_host_cache_enable(int(bool(on))))
     _lib.check(L.amt_host_cache_check(int(bool(check))))
 
 

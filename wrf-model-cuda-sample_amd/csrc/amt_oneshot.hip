@@ -32,12 +32,9 @@ struct HostWorkspace {
     // Residency cache (amt_host_cache_enable): whole-window device copies of the five 3-D inputs that are
     // constant over the acoustic sub-steps of a Runge-Kutta stage -- ww_1, u_1, v_1, t_1, ft -- kept between
     // calls and uploaded again only after amt_host_invalidate.  Keyed on the host pointers and every extent.
-    // Mode 2 adds the in/out state t: the routine's own update is then taken to be the only change of t between
-    // two calls (the kernel updates the resident copy in place; the host copy is what it downloaded from it).
-    static constexpr int NRES = 6;
+    static constexpr int NRES = 5;
     struct Resident {
         bool enabled = false, check = false;
-        int mode = 0;                                         // 0 off, 1 constants, 2 constants + t
         char *buf[NRES] = {};
         size_t bytes_each = 0;
         bool valid[NRES] = {};
@@ -67,11 +64,10 @@ struct HostWorkspace {
         if (arena) (void)hipFree(arena);
         if (stage) (void)hipHostFree(stage);
         const bool en = res.enabled, ck = res.check;
-        const int md = res.mode;
         res.drop();
         if (sw) (void)hipSetDevice(prev);
         *this = HostWorkspace();
-        res.enabled = en; res.check = ck; res.mode = md;     // settings of the thread outlive its buffers
+        res.enabled = en; res.check = ck;                    // settings of the thread outlive its buffers
     }
     // A worker thread's workspace is freed when the thread ends.  The main thread's destructor
     // runs at process exit only, possibly from a signal path with a HIP call on the stack: leave
@@ -156,14 +152,7 @@ extern "C" int amt_host_cache_enable(int on)
             if (st) (void)hipStreamSynchronize(st);
         ws.res.drop();
     }
-    if (on != ws.res.mode && ws.res.enabled && on && ws.device >= 0) {          // another mode: another set of buffers
-        DeviceScope dev(ws.device);
-        for (hipStream_t st : {ws.up, ws.comp, ws.down})
-            if (st) (void)hipStreamSynchronize(st);
-        ws.res.drop();
-    }
     ws.res.enabled = on != 0;
-    ws.res.mode = on < 0 ? 0 : on > 2 ? 2 : on;
     return AMT_OK;
 }
 
@@ -328,25 +317,21 @@ static int amt_host_call(const AmtArgs<T> &h)
     }
     const size_t arena_end = ws.used;
 
-    // ---- residency cache: whole-window copies of ww_1, u_1, v_1, t_1, ft (mode 2: and of the in/out t) ------
-    static const int res_field[HostWorkspace::NRES] = {1, 3, 5, 14, 16, 13};
-    static const char *const res_name[HostWorkspace::NRES] = {"ww_1", "u_1", "v_1", "t_1", "ft", "t"};
+    // ---- residency cache: whole-window copies of ww_1, u_1, v_1, t_1, ft ----------------------------------
+    static const int res_field[HostWorkspace::NRES] = {1, 3, 5, 14, 16};
     int res_of[26];
     for (int f = 0; f < 26; ++f) res_of[f] = -1;
     HostWorkspace::Resident &res = ws.res;
     bool res_upload[HostWorkspace::NRES] = {};
-    // t stays resident only in the regimes that download from the device arrays directly (a packed call brings
-    // its outputs back as one image of the arena, where a resident t is not)
-    const int nres = !res.enabled ? 0 : (res.mode >= 2 && !pack_big) ? 6 : 5;
     if (res.enabled) {
-        const int key[16] = {(int)sizeof(T), h.ims, h.ime, h.kms, h.kme, h.jms, h.jme, w.j_start, w.j_end, p.i0, p.i1, p.nk, device, nres, 0, 0};
+        const int key[16] = {(int)sizeof(T), h.ims, h.ime, h.kms, h.kme, h.jms, h.jme, w.j_start, w.j_end, p.i0, p.i1, p.nk, device, 0, 0, 0};
         const size_t each = r3 * wrow * sizeof(T);
         bool same = res.bytes_each == each && memcmp(res.key, key, sizeof key) == 0;
-        for (int r = 0; r < nres && same; ++r) same = res.host[r] == items[res_field[r]].host;
+        for (int r = 0; r < HostWorkspace::NRES && same; ++r) same = res.host[r] == items[res_field[r]].host;
         if (!same) {
             // another patch, another layout or other arrays: start over (nothing is in flight between calls)
             res.drop();
-            for (int r = 0; r < nres; ++r) {
+            for (int r = 0; r < HostWorkspace::NRES; ++r) {
                 const hipError_t e = hipMalloc((void **)&res.buf[r], each);
                 if (e != hipSuccess) {
                     (void)hipGetLastError();
@@ -358,7 +343,7 @@ static int amt_host_call(const AmtArgs<T> &h)
             res.bytes_each = each;
             memcpy(res.key, key, sizeof key);
         }
-        for (int r = 0; r < nres; ++r) {
+        for (int r = 0; r < HostWorkspace::NRES; ++r) {
             res_of[res_field[r]] = r;
             res_upload[r] = !res.valid[r];
             if (res.check) {
@@ -366,10 +351,10 @@ static int amt_host_call(const AmtArgs<T> &h)
                 const T *rows0 = items[res_field[r]].host + (size_t)(w.j_start - 1 - h.jms) * r3;
                 const uint64_t now_sum = amt_host_sum(rows0, each);
                 if (res.valid[r] && now_sum != res.sum[r]) {
+                    static const char *names[HostWorkspace::NRES] = {"ww_1", "u_1", "v_1", "t_1", "ft"};
                     res.valid[r] = false;
-                    return amt_fail(AMT_ERR_PRECONDITION, "residency cache: %s changed on the host since it was %s "
-                                    "but amt_host_invalidate was not called for it (amt_host_cache_check)", res_name[r],
-                                    r == 5 ? "downloaded" : "uploaded");
+                    return amt_fail(AMT_ERR_PRECONDITION, "residency cache: %s changed on the host since it was uploaded "
+                                    "but amt_host_invalidate was not called for it (amt_host_cache_check)", names[r]);
                 }
                 res.sum[r] = now_sum;
             }
@@ -418,9 +403,7 @@ static int amt_host_call(const AmtArgs<T> &h)
             if (!it.out || it.rank != 3) continue;
             hipMemcpy3DParms cp;
             memset(&cp, 0, sizeof cp);
-            // a resident array (t in mode 2) is read where the kernel wrote it: row c0 - 1 of its whole-window copy
-            T *srcbase = res_of[f] >= 0 ? reinterpret_cast<T *>(res.buf[res_of[f]]) + (size_t)(c0 - 1 - (w.j_start - 1)) * r3 : dev[s][f];
-            cp.srcPtr = make_hipPitchedPtr(srcbase, (size_t)idim * sizeof(T), (size_t)idim, (size_t)kdim);
+            cp.srcPtr = make_hipPitchedPtr(dev[s][f], (size_t)idim * sizeof(T), (size_t)idim, (size_t)kdim);
             cp.dstPtr = make_hipPitchedPtr(const_cast<T *>(it.host), (size_t)idim * sizeof(T), (size_t)idim, (size_t)kdim);
             cp.srcPos = make_hipPos((size_t)p.i0 * sizeof(T), (size_t)p.k1, 1);
             cp.dstPos = make_hipPos((size_t)p.i0 * sizeof(T), (size_t)p.k1, (size_t)(c0 - h.jms));
@@ -584,11 +567,8 @@ static int amt_host_call(const AmtArgs<T> &h)
         if (e != hipSuccess && rc == AMT_OK)
             rc = amt_fail(AMT_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
     }
-    if (res.enabled) {
-        for (int r = 0; r < nres; ++r) res.valid[r] = (rc == AMT_OK);
-        if (nres == 6 && res.check && rc == AMT_OK)          // t: what the host holds now is what the device holds
-            res.sum[5] = amt_host_sum(h.t + (size_t)(w.j_start - 1 - h.jms) * r3, r3 * wrow * sizeof(T));
-    }
+    if (res.enabled)
+        for (int r = 0; r < HostWorkspace::NRES; ++r) res.valid[r] = (rc == AMT_OK);
     if (trace)
         fprintf(stderr, "amt one-shot: %d chunk(s) of %ld rows, 3-D %s%s, small arrays %s; alloc %.2f ms, enqueue %.2f ms, drain %.2f ms\n",
                 nchunk, rows, pinned ? "pinned" : pack_big ? "packed" : "pageable", threaded ? " + download thread" : "",
