@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 column, 2 march")
     ap.add_argument("--seed", type=int, default=12345)
-    ap.add_argument("--probe-placements", type=int, default=3,
+    ap.add_argument("--probe-placements", type=int, default=5,
                     help="allocate the state this many times (one after the other), time 2 sweeps on each and keep "
                          "the fastest: the sweep time depends on which physical pages the driver hands out (up to 5 %% "
                          "between allocations, stable within one); every timing is reported; 1 = take the first "
