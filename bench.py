@@ -675,8 +675,9 @@ def run_rank(a):
         # first send/recv between two ranks builds their channels, which takes seconds);
         # the inputs are static, so an extra exchange changes nothing
         def first_exchange():
+            torch.cuda.set_device(device)              # the helper thread has its own current device
             stepper.exchange_halos()
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(device)
         try:
             watchdog(first_exchange, a.comm_timeout, "first halo exchange (RCCL connection set-up)")
         except Exception as e:  # noqa: BLE001  (a rank that cannot exchange must not leave its peers waiting for ever)
