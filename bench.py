@@ -59,6 +59,9 @@ def parse():
                     help="i padding of the resident layout: i = its sits this many elements into a row")
     ap.add_argument("--no-overlap", action="store_true", help="exchange halos before computing (no 2nd stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not re-measure the HBM traffic of a launch with two rocprofv3 --pmc child passes after the "
+                         "timed sweeps (N = 1 only; roofline.traffic then is the recorded value of profiles/hbm_traffic.json)")
     ap.add_argument("--no-box-probe", action="store_true",
                     help="skip the in-process streaming ceilings (roofline.box_*) and the clock / power snapshot")
     ap.add_argument("--no-verify", action="store_true")
@@ -161,6 +164,60 @@ def box_ceilings(pkg, stream, device, nbytes=4 << 30):
     del src, dst
     torch.cuda.empty_cache()
     return out, under_load
+
+
+def measure_traffic(a, seconds=150.0):
+    """HBM bytes of one launch ON THIS BOX, in this run: two child runs of this same script (two sweeps each) under
+    `rocprofv3 --kernel-trace --kernel-include-regex amt_ --pmc FETCH_SIZE` / `... WRITE_SIZE` -- separate passes, the
+    program directly after `--`, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- and the gfx950 correction of
+    profiles/README.md (FETCH_SIZE counts half of a streamed read).  Returns (read_bytes, write_bytes, note) or raises;
+    the caller has released its own arrays first.  Each pass is its own process group under a timeout."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        raise RuntimeError("rocprofv3 not on PATH")
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="amt_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--output-format", "csv", "--kernel-trace", "--kernel-include-regex", "amt_march|amt_column",
+               "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, str(Path(__file__).resolve()),
+               "--ni", str(a.ni), "--nk", str(a.nk), "--nj", str(a.nj), "--dtype", a.dtype, "--variant", str(a.variant),
+               "--seed", str(a.seed), "--align-elems", str(a.align_elems), "--idim-extra", str(a.idim_extra),
+               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-verify", "--no-box-probe",
+               "--probe-placements", "1", "--no-traffic"]
+        p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp",
+                             env=dict(os.environ, TMPDIR="/tmp"), start_new_session=True)
+        try:
+            p.wait(timeout=seconds)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            p.wait()
+            shutil.rmtree(out, ignore_errors=True)
+            raise RuntimeError(f"the {counter} pass did not finish in {seconds:.0f} s")
+        vals = []
+        for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    if r.get("Counter_Name") == counter and "amt_" in r.get("Kernel_Name", ""):
+                        vals.append(float(r["Counter_Value"]))
+        shutil.rmtree(out, ignore_errors=True)
+        if p.returncode != 0 or not vals:
+            raise RuntimeError(f"the {counter} pass gave no data (exit {p.returncode})")
+        got[counter] = (sum(vals) / len(vals), len(vals))
+    rd = 2.0 * got["FETCH_SIZE"][0] * 1024.0
+    wr = got["WRITE_SIZE"][0] * 1024.0
+    note = (f"measured in this run on this box: child runs of this command under rocprofv3 --kernel-trace --pmc FETCH_SIZE and "
+            f"--pmc WRITE_SIZE (separate passes, {got['FETCH_SIZE'][1]} + {got['WRITE_SIZE'][1]} launches; KiB per launch "
+            f"{got['FETCH_SIZE'][0]:.0f} / {got['WRITE_SIZE'][0]:.0f}); HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 "
+            f"calibration of profiles/README.md")
+    return rd, wr, note
 
 
 def algorithmic_bytes(ni, nk, nj, itemsize):
@@ -826,6 +883,26 @@ def run_rank(a):
             out["fp32_vs_fp64_oracle"] = {"max_abs_err_over_field_scale": float(f"{fp32_err:.3e}"),
                                           "stated_tolerance": 2e-5,
                                           "within_tolerance": bool(fp32_err <= 2e-5)}
+        if world == 1 and not a.no_traffic:
+            # same-run, same-box HBM traffic: this process gives its arrays back first
+            rf = out["roofline"]
+            try:
+                del stepper, dev
+                torch.cuda.empty_cache()
+                rd_m, wr_m, note = measure_traffic(a)
+                rf["traffic_recorded"], rf["traffic_recorded_source"] = rf.get("traffic"), rf.get("traffic_source")
+                rf["traffic"], rf["traffic_source"] = int(rd_m + wr_m), note
+                rf["traffic_read_bytes"], rf["traffic_write_bytes"] = int(rd_m), int(wr_m)
+                rf["traffic_over_algorithmic"] = round((rd_m + wr_m) / abytes, 4)
+                if ceilings and "box_copy_GBps" in ceilings:
+                    cp, rdr = ceilings["box_copy_GBps"], ceilings["box_read_GBps"]
+                    inv_w = max(2.0 / cp - 1.0 / rdr, 1.0 / rdr)
+                    mixed_ms = (rd_m / rdr + wr_m * inv_w) / 1e6
+                    rf["box_mixed_ceiling_ms"] = round(mixed_ms, 4)
+                    rf["frac_of_box_copy"] = round((rd_m + wr_m) / ev_per_step_s / 1e9 / cp, 4)
+                    rf["frac_of_box_mixed"] = round(mixed_ms / (ev_per_step_s * 1e3), 4)
+            except Exception as e:  # noqa: BLE001  (the recorded value stays, and the line says why)
+                rf["traffic_same_run_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(dims, a.dtype, a.seed, a.cpu_rows, a.cpu_seconds)

@@ -106,3 +106,39 @@ def test_random_cases_match_oracle(pkg, oracle):
     if out.is_dir():
         (out / f"random_campaign_{N_CASES}.json").write_text(json.dumps(summary, indent=1) + "\n")
     assert ran["march"] >= N_CASES * 0.8 and ran["column"] >= N_CASES * 0.95
+
+
+# cases the long campaigns have found (bounds in the order of synth.INT_NAMES, flags, dtype, register flavour?)
+REGRESSIONS = [
+    # seed 777, case 47199 (r03): fp32 with two columns per lane in the REGISTER flavour on 602-element rows whose
+    # window starts at the odd memory column 53: tiles anchored there left the row's last column outside every staged
+    # pair and the window's last column read an unwritten t_1(i+1)
+    ((1, 549, 1, 4, 34, -52, 549, -1, 5, 0, 34, 1, 549, 1, 4, 1, 34), dict(periodic_x=True, specified=True, nested=True), np.float32, True),
+    ((1, 549, 1, 4, 34, -52, 549, -1, 5, 0, 34, 1, 549, 1, 4, 1, 34), dict(periodic_x=True, specified=True, nested=True), np.float32, False),
+    ((1, 549, 1, 4, 34, -51, 549, -1, 5, 0, 34, 1, 549, 1, 4, 1, 34), dict(periodic_x=True), np.float32, True),      # odd row length
+    ((1, 549, 1, 4, 61, -52, 549, -1, 5, 0, 61, 1, 549, 1, 4, 1, 61), dict(), np.float64, True),
+]
+
+
+@pytest.mark.parametrize("case", range(len(REGRESSIONS)))
+def test_cases_found_by_the_campaigns_stay_fixed(pkg, oracle, case):
+    import torch
+    bounds, flags, dtype, register_flavour = REGRESSIONS[case]
+    S = pkg.synth
+    L = pkg.load_library()
+    b = S.Bounds(*bounds)
+    dims = (b.ide - b.ids, b.kde - 1, b.jde - b.jds)
+    host = S.make_patch(b, pkg.GridConfig(**flags), dtype=dtype, seed=48199, global_dims=dims)
+    want = host.copy()
+    oracle.advance_mu_t(*want.args())
+    try:
+        L.amt_march_force_shape(0, 0, 0, -1, 0 if register_flavour else 1, 0, 0)
+        for variant in (pkg.VARIANT_MARCH, pkg.VARIANT_AUTO):
+            dev = host.to_device("cuda:0")
+            pkg.advance_mu_t(*dev.args(), variant=variant)
+            torch.cuda.synchronize()
+            got = dev.to_host()
+            for n in S.FIELD_NAMES:
+                assert bits_equal(got.arrays[n], want.arrays[n]), (case, variant, n, L.amt_march_last_kernel().decode())
+    finally:
+        L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)

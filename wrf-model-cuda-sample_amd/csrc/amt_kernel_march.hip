@@ -1145,7 +1145,11 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
         // two columns per lane on an odd row length: the last lane of a row straddles its end; it is never a
         // window lane, its t_1 / v come by DMA chunks, its 2-D column is staged element-wise -- but the
         // register flavour stages rows by lane vectors and needs an even length
-        if (s.vw > 1 && !s.dma && p.idim % s.vw != 0) return false;
+        // -- counted from the FIRST TILE'S column 0: tiles that start at an odd window column (rows that are not
+        // whole lines, amt_march_col_lo) would leave the row's last column outside every staged pair, and the
+        // window's last column then reads a t_1(i+1) nobody wrote (found by the randomised campaign, seed 777
+        // case 47199: fp32, 602-element rows, window from column 53)
+        if (s.vw > 1 && !s.dma && (p.idim - amt_march_col_lo(p)) % s.vw != 0) return false;
         return amt_march_shape_feasible(wb, s, nk) && amt_march_find<T>(s) != nullptr;
     };
     if (env.kpt || env.hl || env.vw || env.xd >= 0 || env.wm) {
