@@ -220,6 +220,45 @@ def measure_traffic(a, seconds=150.0):
     return rd, wr, note
 
 
+def ramp_clocks(pkg, stream, tensor, max_seconds=3.0):
+    """Bring the GPU out of its idle power state before the warm-up sweeps.  The verification of the first sweep is a
+    second or two of CPU work during which the GPU goes to sleep clocks (sysfs: sclk `S: 116Mhz`), and it takes longer to
+    come back than W = 5 warm-up sweeps last (75 ms): a run whose 20 timed sweeps averaged 16.44 ms had a MEDIAN of
+    15.37 ms.  A read-only stream over one of the state's own arrays (nothing is written) runs in batches of ~50 ms until
+    two consecutive batches agree to 1 % (at least four, at most max_seconds).  Returns what it saw, for the line."""
+    import ctypes
+    import torch
+    L = pkg.load_library()
+    nb = tensor.numel() * tensor.element_size() // 16 * 16
+    if nb < (1 << 20):
+        return None
+    sink = torch.zeros(8, dtype=torch.float64, device=tensor.device)
+    h = ctypes.c_void_p(stream.cuda_stream)
+    per_batch = max(4, int(0.05 / max(nb / 6.0e12, 1e-6)))            # ~50 ms at 6 TB/s
+    rates, t_begin = [], time.perf_counter()
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(per_batch):
+            pkg.lib.check(L.amt_calib_stream_rate(h, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(tensor.data_ptr()),
+                                                  ctypes.c_size_t(nb), 1))
+        e1.record(stream)
+        e1.synchronize()
+        rates.append(per_batch * nb / e0.elapsed_time(e1) / 1e6)
+        steady = len(rates) >= 4 and abs(rates[-1] - rates[-2]) <= 0.01 * rates[-1] and abs(rates[-2] - rates[-3]) <= 0.01 * rates[-2]
+        if steady or time.perf_counter() - t_begin > max_seconds:
+            break
+    # one more batch, and the clocks as sysfs shows them in the middle of it (steady state under load)
+    for _ in range(per_batch):
+        pkg.lib.check(L.amt_calib_stream_rate(h, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(tensor.data_ptr()),
+                                              ctypes.c_size_t(nb), 1))
+    time.sleep(0.015)
+    clocks = gpu_state_sysfs(tensor.device.index or 0)
+    torch.cuda.synchronize(tensor.device)
+    return {"batches": len(rates), "seconds": round(time.perf_counter() - t_begin, 3), "first_batch_GBps": round(rates[0], 1),
+            "last_batch_GBps": round(rates[-1], 1), "slowest_batch_GBps": round(min(rates), 1), "clocks_at_the_end": clocks}
+
+
 def algorithmic_bytes(ni, nk, nj, itemsize):
     """Compulsory HBM traffic of one sweep (SURVEY.md section 8a / BASELINE.md section 3)."""
     return itemsize * ni * nj * (11 * nk + 14)
@@ -756,6 +795,12 @@ def run_rank(a):
         verified, why = verify_first_sweep(pkg, oracle, dev, gb, dims, dtype, a.seed, (sb.jts, sb.jte))
         if a.dtype == "f32" and rank == 0:
             fp32_err = fp32_error_vs_fp64(pkg, oracle, dev, gb, dims, a.seed, (sb.jts, sb.jte))
+    clock_ramp = None
+    if not a.no_box_probe:
+        try:
+            clock_ramp = ramp_clocks(pkg, main_stream, dev.arrays["u"])
+        except Exception as e:  # noqa: BLE001
+            clock_ramp = {"error": f"{type(e).__name__}: {e}"}
     for _ in range(a.warmup - warm_done):
         stepper.step()
 
@@ -826,6 +871,7 @@ def run_rank(a):
             "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "ms_per_step_median": round(float(np.median(per_sweep)), 4) if per_sweep else None,   # rank 0's sweeps
+            "per_sweep_ms": [round(x, 3) for x in per_sweep] if len(per_sweep) <= 100 else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -876,7 +922,8 @@ def run_rank(a):
         elif ceilings:
             out["roofline"]["box_error"] = ceilings.get("error")
         if smi_idle is not None or clocks_under_load is not None:
-            out["gpu_state"] = {"idle_before_run": smi_idle, "under_load_sysfs": clocks_under_load}
+            out["gpu_state"] = {"idle_before_run": smi_idle, "under_load_sysfs": clocks_under_load,
+                                "clock_ramp_before_warmup": clock_ramp}
         if why:
             out["verify_message"] = why
         if fp32_err is not None:
