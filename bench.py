@@ -221,11 +221,14 @@ def measure_traffic(a, seconds=150.0):
 
 
 def ramp_clocks(pkg, stream, tensor, max_seconds=3.0):
-    """Bring the GPU out of its idle power state before the warm-up sweeps.  The verification of the first sweep is a
-    second or two of CPU work during which the GPU goes to sleep clocks (sysfs: sclk `S: 116Mhz`), and it takes longer to
-    come back than W = 5 warm-up sweeps last (75 ms): a run whose 20 timed sweeps averaged 16.44 ms had a MEDIAN of
-    15.37 ms.  A read-only stream over one of the state's own arrays (nothing is written) runs in batches of ~50 ms until
-    two consecutive batches agree to 1 % (at least four, at most max_seconds).  Returns what it saw, for the line."""
+    """Make sure the GPU is out of its idle power state before the warm-up sweeps, and record that it is: the
+    verification of the first sweep is a second or two of CPU work during which the GPU idles, and W = 5 warm-up sweeps
+    last only 75 ms.  A read-only stream over one of the state's own arrays (nothing is written) runs in batches of
+    ~50 ms until two consecutive batches agree to 1 % (at least four, at most max_seconds).  On the boxes seen so far the
+    first batch already streams at the last one's rate (no ramp), and the 20 timed sweeps that follow are flat to 0.3 %
+    (`per_sweep_ms`); one earlier line whose mean was 16.44 ms against a median of 15.37 had no per-sweep record to say
+    which sweeps were slow -- now every line has.  (sysfs's sclk is NOT a witness: it reads `S: 100Mhz` in the middle of
+    a 6.9 TB/s stream on this pool.)  Returns what it saw, for the line."""
     import ctypes
     import torch
     L = pkg.load_library()
