@@ -91,7 +91,11 @@ def test_single_gpu_line_carries_the_contract_keys():
     for key in ("box_copy_GBps", "box_read_GBps", "box_mixed_ceiling_ms", "frac_of_box_copy", "frac_of_box_mixed"):
         assert key in rf and rf[key] > 0, key
     assert 2000 < rf["box_copy_GBps"] < 8000 and rf["box_read_GBps"] >= 0.9 * rf["box_copy_GBps"]
-    assert "gpu_state" in out
+    assert "gpu_state" in out and "clock_ramp_before_warmup" in out["gpu_state"]
+    assert len(out["per_sweep_ms"]) == out["steps"]
+    # the HBM traffic of a launch is re-measured in the run (two rocprofv3 --pmc child passes), or the line says why not
+    assert rf.get("traffic_same_run_error") or (rf["traffic"] and 0.9 < rf["traffic_over_algorithmic"] < 1.5
+                                                and rf["traffic_source"].startswith("measured in this run"))
     assert out["config"]["placement_probe_ms"] is None or len(out["config"]["placement_probe_ms"]) >= 2
 
 
