@@ -180,6 +180,8 @@ def measure_traffic(a, seconds=150.0):
     import tempfile
     if shutil.which("rocprofv3") is None:
         raise RuntimeError("rocprofv3 not on PATH")
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("this process is itself running under a profiler: no nested rocprofv3 passes")
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="amt_pmc_", dir="/tmp")
