@@ -69,8 +69,18 @@ def test_forced_shape_matches_oracle(pkg, oracle, force, shape):
             # unaligned: minimal memory, an ODD row length (ni + 2) whose last column is the window's
             # i+1 neighbour -- the LDS-DMA takes it as it is (no alignment of the DMA source is needed)
             b = S.domain_bounds(ni, nk, 7, aligned=aligned)
-            if not aligned and vw == 2 and not dma and b.idim % 2:
-                b = b.replace(ime=b.ime + 1)        # register flavour with two columns per lane: even rows
+            if not aligned and vw == 2 and not dma:
+                # register flavour with two columns per lane: whole pairs from the first tile's column 0 (the window's
+                # first column when rows are not whole 128-byte lines, else that column rounded down to a line) to
+                # the row end
+                def col_lo(bb):
+                    line = 128 // np.dtype(dtype).itemsize
+                    i0 = bb.its - bb.ims
+                    return i0 if bb.idim % line else i0 // line * line
+                for _ in range(3):
+                    if (b.idim - col_lo(b)) % 2 == 0:
+                        break
+                    b = b.replace(ime=b.ime + 1)
             host = S.make_patch(b, cfg, dtype=dtype, seed=100 + nk, global_dims=(ni, nk, 7))
             want = host.copy()
             oracle.advance_mu_t(*want.args())
