@@ -75,7 +75,8 @@ def test_forced_shape_matches_oracle(pkg, oracle, force, shape):
                 # the row end
                 def col_lo(bb):
                     line = 128 // np.dtype(dtype).itemsize
-                    i0 = bb.its - bb.ims
+                    i_start = pkg.compute_window(cfg, bb.ids, bb.ide, bb.jds, bb.jde, bb.its, bb.ite, bb.jts, bb.jte, bb.kts, bb.kte)[0]
+                    i0 = i_start - bb.ims                 # the window's first column (the boundary flags move it)
                     return i0 if bb.idim % line else i0 // line * line
                 for _ in range(3):
                     if (b.idim - col_lo(b)) % 2 == 0:
