@@ -30,9 +30,12 @@ sys.path.insert(0, str(HERE.parent))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--impl", choices=("c", "fortran", "reference_nodump", "reference"), required=True)
+    ap.add_argument("--impl", choices=("c", "fortran", "reference_nodump", "reference"))
+    ap.add_argument("--prebuild", action="store_true",
+                    help="only build the -march=native libraries of THIS machine (oracle/_native/<cpu>/) and exit: "
+                         "compile time is never charged to a measurement's budget or timeout")
     ap.add_argument("--dtype", choices=("f32", "f64"), default="f64")
-    ap.add_argument("--size", type=int, nargs=3, required=True, metavar=("NI", "NK", "NJ"))
+    ap.add_argument("--size", type=int, nargs=3, metavar=("NI", "NK", "NJ"))
     ap.add_argument("--threads", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=2.0, help="time budget of the timed sweeps")
     ap.add_argument("--gj0", type=int, default=0, help="global row of the slab's first memory row")
@@ -43,6 +46,21 @@ def main():
     spec = importlib.util.spec_from_file_location("amt_oracle", HERE / "oracle.py")
     O = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(O)
+    if a.prebuild:
+        t0 = time.perf_counter()
+        built, failed = [], []
+        for what, fn in (("fortran_f64", lambda: O.fortran_lib(8, native=True)), ("fortran_f32", lambda: O.fortran_lib(4, native=True)),
+                         ("bench_llvm", O.bench_llvm_lib), ("bench_gcc", O.bench_lib)):
+            try:
+                fn()
+                built.append(what)
+            except Exception as e:  # noqa: BLE001  (a compiler that is not there costs its entries, nothing else)
+                failed.append(f"{what}: {type(e).__name__}: {str(e)[-200:]}")
+        print(json.dumps({"prebuild": built, "failed": failed, "seconds": round(time.perf_counter() - t0, 2),
+                          "dir": str(O._native_dir())}), flush=True)
+        return
+    if not a.impl or not a.size:
+        ap.error("--impl and --size are required")
     dtype = np.float64 if a.dtype == "f64" else np.float32
     ni, nk, nj = a.size
     cells = ni * nk * nj

@@ -7,14 +7,22 @@
 !
 !   * ONE pass over j instead of the reference's three (ww/mu :112-172, theta pre-update :208-215,
 !     flux-form theta :217-250): a column never reads another column's outputs (SURVEY.md section 3),
-!     so row j is finished -- mass, omega, theta -- before row j+1 is touched, and ww, t, t_1, u, v
-!     of the row are still in cache when the theta update needs them;
-!   * i is blocked (IB columns) so that the two k-column scratch arrays stay in L1/L2 and live on
-!     the calling thread's stack (the reference's (its:ite,kts:kte) automatics are 2 x 2 MB at 4096
-!     columns);
+!     so row j is finished -- mass, omega, theta -- before row j+1 is touched;
+!   * i is blocked (AMT_IB columns) and the blocks MARCH in j (i block outer, j inner -- the order of the
+!     GPU kernel): rows j and j+1 of v, v_1 and rows j-1, j, j+1 of t_1 of a block stay in the core's
+!     cache from one row to the next, so every input element comes from memory once (with j outer and
+!     the blocks inner, as in r03, a whole row of all blocks passed between two uses and v, v_1 were
+!     fetched twice, t_1 three times: 18 words per cell against 14 now, write-allocates included);
+!   * the omega recurrence (:159-163), its perturbation form (:168-172) and the vertical theta flux
+!     (:224-229) are ONE k loop: ww is written once and never read back (the un-subtracted value of the
+!     level below is carried in a per-column scalar, exactly the value the reference reads from ww(k-1));
+!   * the k-column scratch lives on the calling thread's stack (the reference's (its:ite,kts:kte)
+!     automatics are 2 x 2 MB at 4096 columns);
 !   * no debug dumps (:175-189 are a side effect of the sample, 99.6 % of its wall time);
 !   * OpenMP over j-tiles in the C-callable drivers below: every thread calls the routine with its own
 !     jts:jte, the scheme sketched in the reference driver (advance_mu_t_driver.f90:175-209).
+!
+! Build knobs (-cpp): AMT_IB columns per i block (default 256), AMT_J_OUTER=1 the r03 loop order (A/B only).
 !
 ! Every expression keeps the reference's association and the file is compiled with
 ! -ffp-contract=off, so the results are the reference's bits: tests/test_fortran_cpu.py holds it
@@ -26,7 +34,10 @@ module advance_mu_t_cpu_mod
   implicit none
   private
   public :: advance_mu_t_cpu
-  integer, parameter :: IB = 128          ! columns per i block (scratch: 2 x IB x kde reals)
+#ifndef AMT_IB
+#define AMT_IB 256
+#endif
+  integer, parameter :: IB = AMT_IB       ! columns per i block (scratch: 2 x IB x kde reals)
 
 contains
 
@@ -57,6 +68,7 @@ contains
     real :: div(IB, kts:kte)      ! horizontal mass-flux divergence of the block's columns
     real :: flx(IB, kts:kte+1)    ! vertical theta flux at the level interfaces
     real :: colsum(IB)            ! its column integral
+    real :: wwu(IB)               ! omega of the recurrence (:161) at the current level, before :170
     real :: old_mu
     integer :: i, j, k, ib0, ib1, n, ic
     integer :: i_lo, i_hi, j_lo, j_hi, k_hi
@@ -78,8 +90,13 @@ contains
       j_hi = min(jte, jde - 2)
     end if
 
+#if AMT_J_OUTER
     do j = j_lo, j_hi
       do ib0 = i_lo, i_hi, IB
+#else
+    do ib0 = i_lo, i_hi, IB
+      do j = j_lo, j_hi
+#endif
         ib1 = min(ib0 + IB - 1, i_hi)
         n = ib1 - ib0 + 1
 
@@ -107,27 +124,21 @@ contains
           muave(i, j) = .5 * ((1. + epssm) * mu(i, j) + (1. - epssm) * old_mu)
         end do
 
-        ! --- omega: upward recurrence from the incoming ww(:,1,:), then the perturbation form
-        !     (reference :159-172; the subtraction runs after the whole recurrence) ---
-        do k = 2, k_hi
-          do ic = 1, n
-            i = ib0 + ic - 1
-            ww(i, k, j) = ww(i, k-1, j) - dnw(k-1) * (colsum(ic) + div(ic, k-1) + mu_tend(i, j)) / msfty(i, j)
-          end do
-        end do
-        do k = 1, k_hi
-          do ic = 1, n
-            i = ib0 + ic - 1
-            ww(i, k, j) = ww(i, k, j) - ww_1(i, k, j)
-          end do
-        end do
-
-        ! --- vertical theta flux at the interfaces (reference :219-229) ---
+        ! --- omega: upward recurrence from the incoming ww(:,1,:) (reference :159-163), the perturbation
+        !     form (:168-172; it runs after the whole recurrence, so the recurrence sees the un-subtracted
+        !     value below: carried in wwu), and the vertical theta flux at the interfaces (:219-229) ---
         flx(1:n, 1) = 0.
         flx(1:n, kde) = 0.
+        do ic = 1, n
+          i = ib0 + ic - 1
+          wwu(ic) = ww(i, 1, j)
+          ww(i, 1, j) = wwu(ic) - ww_1(i, 1, j)
+        end do
         do k = 2, k_hi
           do ic = 1, n
             i = ib0 + ic - 1
+            wwu(ic) = wwu(ic) - dnw(k-1) * (colsum(ic) + div(ic, k-1) + mu_tend(i, j)) / msfty(i, j)
+            ww(i, k, j) = wwu(ic) - ww_1(i, k, j)
             flx(ic, k) = ww(i, k, j) * (fnm(k) * t_1(i, k, j) + fnp(k) * t_1(i, k-1, j))
           end do
         end do

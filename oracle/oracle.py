@@ -47,9 +47,12 @@ INT_NAMES = ("ids", "ide", "jds", "jde", "kde", "ims", "ime", "jms", "jme", "kms
              "its", "ite", "jts", "jte", "kts", "kte")
 
 
-def build(ref: bool | None = None) -> None:
-    """Compile the C restatement, and the reference build when its sources exist."""
+def build(ref: bool | None = None, extras: bool = False) -> None:
+    """Compile the C restatement (the checker: gcc only), on request the timing builds and the Fortran CPU
+    path (amdclang, amdflang), and the reference build when its sources exist."""
     subprocess.run(["make", "-C", str(HERE), "all"], check=True, capture_output=True)
+    if extras:
+        subprocess.run(["make", "-C", str(HERE), "extras"], check=True, capture_output=True)
     if ref is None:
         ref = Path("/root/reference/module_small_step_em.f90").exists()
     if ref:
@@ -102,7 +105,10 @@ def fortran_lib(itemsize: int, native: bool = False) -> ctypes.CDLL:
     (what bench.py times; same bits, tests/test_fortran_cpu.py)."""
     key = (itemsize, native)
     if key not in _fortran_libs:
-        if native:
+        override = os.environ.get("AMT_FORTRAN_CPU_DIR")           # A/B builds (profiles/cpu_fortran_tune.sh)
+        if override:
+            path = Path(override) / FORTRAN_CPU_PATHS[itemsize].name
+        elif native:
             out = _native_dir()
             path = out / FORTRAN_CPU_PATHS[itemsize].name
             src = HERE / "fortran" / "advance_mu_t_cpu.f90"

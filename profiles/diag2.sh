@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/diag2; mkdir -p $O
-timeout 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_shapes.py tests/test_gpu_random.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+timeout 900 python3 -m pytest tests/test_gpu_10_parity.py tests/test_gpu_11_shapes.py tests/test_gpu_12_random.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 timeout 900 ./profiles/vmm_probe > $O/vmm.jsonl 2> $O/vmm.err
 timeout 1200 python3 profiles/sweep.py > $O/size_sweep.md 2> $O/size_sweep.err
 rocprofv3 --output-format csv --kernel-trace --pmc TCC_EA0_RDREQ -d $O/chan_rd -o chan -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $O/chan_rd.log 2>&1

@@ -2,7 +2,7 @@
 # r03 diagnostic pass 4 (GPU box): tapered block schedule -- parity, then A/B against uniform blocks
 set -u
 O=gpurun_out/diag4; mkdir -p $O
-timeout 1200 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_shapes.py tests/test_gpu_random.py tests/test_gpu_fullsize.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+timeout 1200 python3 -m pytest tests/test_gpu_10_parity.py tests/test_gpu_11_shapes.py tests/test_gpu_12_random.py tests/test_gpu_13_fullsize.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 A="python3 profiles/ab_shapes.py"
 $A --ni 4096 --nk 60 --nj 512 --inner 20 t0 t1 t48 t32 t24 t16 > $O/j512.txt 2>&1
 $A --ni 4096 --nk 60 --nj 510 --inner 20 t0 t1 t32 > $O/j510.txt 2>&1

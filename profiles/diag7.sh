@@ -2,7 +2,7 @@
 # r03 pass 7 (GPU box): residency cache (tests + timing), WRF-native rows with window-anchored tiles, full-size tests
 set -u
 O=gpurun_out/diag7; mkdir -p $O
-timeout 900 python3 -m pytest tests/test_gpu_host_cache.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py tests/test_gpu_random.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+timeout 900 python3 -m pytest tests/test_gpu_20_host_cache.py tests/test_gpu_13_fullsize.py tests/test_gpu_10_parity.py tests/test_gpu_12_random.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 python3 profiles/oneshot.py --ni 1024 --nk 60 --nj 1024 > $O/oneshot_1024_f64.json 2> $O/oneshot_1024_f64.err
 python3 profiles/oneshot.py --ni 512 --nk 60 --nj 512 > $O/oneshot_512_f64.json 2> $O/oneshot_512_f64.err
 python3 profiles/oneshot.py --ni 2048 --nk 60 --nj 2048 > $O/oneshot_2048_f64.json 2> $O/oneshot_2048_f64.err

@@ -16,6 +16,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _order_group(item):
+    """Collection order of a `-x` run: the oracle-parity files first (test_gpu_00_configs: one test per BASELINE.json
+    config; then parity, shapes, the random campaign, full sizes, host paths, slabs, replay), every other file after
+    them, and the files that start child processes, launchers and rendezvous (test_gpu_9*: bench.py, torch.distributed.run)
+    last -- an infrastructure test can then never stop the run before parity has been checked."""
+    name = Path(str(item.fspath)).name
+    if name.startswith("test_gpu_9"):
+        return (2, name)
+    if name.startswith("test_gpu_"):
+        return (0, name)
+    return (1, name)
+
+
+def pytest_collection_modifyitems(session, config, items):
+    items.sort(key=_order_group)          # stable: the order inside a file is kept
+
+
 @pytest.fixture(scope="session")
 def entry():
     import __graft_entry__ as g

@@ -128,3 +128,15 @@ def test_cpu_baseline_failures_cost_an_entry_not_the_line(monkeypatch, tmp_path)
     monkeypatch.setattr(b, "ROOT", tmp_path)                 # no oracle/cpu_bench.py there: every child fails
     out = b.cpu_baseline((64, 8, 32), "f64", 1, 8, 3.0)
     assert out["value"] is None and out["errors"] and out["kind"] == "port"
+
+
+def test_cpu_baseline_reports_the_fastest_path_and_builds_outside_the_budget():
+    """The leg compiles this machine's -march=native libraries in its own child BEFORE the budget starts
+    (r03: a cold box's compile ate the first entry's timeout and `value` came back null), and `value` is the
+    faster of the Fortran CPU path and the C port on the same slab."""
+    b = _bench()
+    out = b.cpu_baseline((64, 8, 32), "f64", 1, 8, 6.0)
+    assert out["value"] and out["value"] > 0, out.get("errors")
+    assert out["value"] == max(x for x in (out["fortran_Mcells_s"], out["port_c_Mcells_s"]) if x)
+    assert out["impl"].startswith(("fortran", "port_c")) and "build_seconds_not_in_the_budget" in out
+    assert {m["impl"] for m in out["matrix"]} >= {"fortran", "port_c"}

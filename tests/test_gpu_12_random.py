@@ -98,7 +98,7 @@ def test_random_cases_match_oracle(pkg, oracle):
             ran["oneshot_cached"] += 1
     L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
     summary = {"seed": SEED, "cases": N_CASES, "wall_s": round(time.time() - t_start, 1), "ran": ran, "failures": 0,
-               "what": "tests/test_gpu_random.py: random extents (to 700 columns, 300 levels), paddings, sub-tiles, flags, "
+               "what": "tests/test_gpu_12_random.py: random extents (to 700 columns, 300 levels), paddings, sub-tiles, flags, "
                        "precisions; march (LDS-DMA / register flavour) and column kernels, one-shot, cached one-shot; "
                        "bit-exact against the oracle"}
     print("random campaign:", json.dumps(summary))

@@ -5,7 +5,7 @@ array changed WITHOUT an invalidate is caught by the checksum mode, and is picke
 import numpy as np
 import pytest
 
-from test_gpu_parity import assert_patch_equal
+from test_gpu_10_parity import assert_patch_equal
 
 pytestmark = pytest.mark.gpu
 

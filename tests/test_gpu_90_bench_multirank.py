@@ -85,8 +85,15 @@ def test_single_gpu_line_carries_the_contract_keys():
     assert out["cpu_baseline"]["kind"] in ("port", "reference") and out["cpu_baseline"]["cores"] >= 1
     # the CPU baseline is the Fortran CPU path, one child process per entry
     cb = out["cpu_baseline"]
-    assert cb["impl"].startswith("fortran") and cb["value"] and cb["value"] > 0
-    assert any(m["impl"] == "fortran" for m in cb["matrix"]) and cb["leg_seconds"] < 60
+    assert "error" not in cb, cb
+    # the native CPU libraries are compiled by their own child outside the leg's budget (a cold box needs 20-40 s for
+    # them); whatever else goes wrong is in `errors` and is shown here
+    assert cb["value"] and cb["value"] > 0, (cb.get("errors"), cb.get("build_seconds_not_in_the_budget"), cb.get("matrix"))
+    assert cb["impl"].startswith(("fortran", "port_c")), cb["impl"]
+    slab_entries = [m["Mcells_s"] for m in cb["matrix"] if "j-slab" in m["size"]]
+    assert slab_entries and cb["value"] >= max(slab_entries) - 1e-6, (cb["value"], slab_entries)      # the fastest CPU path is the baseline
+    assert any(m["impl"] == "fortran" for m in cb["matrix"]), (cb.get("errors"), cb["matrix"])
+    assert cb["leg_seconds"] < 60
     # attribution: this box's own streaming rates and what they make of the launch
     for key in ("box_copy_GBps", "box_read_GBps", "box_mixed_ceiling_ms", "frac_of_box_copy", "frac_of_box_mixed"):
         assert key in rf and rf[key] > 0, key
@@ -97,6 +104,10 @@ def test_single_gpu_line_carries_the_contract_keys():
     assert rf.get("traffic_same_run_error") or (rf["traffic"] and 0.9 < rf["traffic_over_algorithmic"] < 1.5
                                                 and rf["traffic_source"].startswith("measured in this run"))
     assert out["config"]["placement_probe_ms"] is None or len(out["config"]["placement_probe_ms"]) >= 2
+    if out["config"]["placement_probe_ms"]:
+        pl = out["placement"]
+        assert pl["ms_per_step_placement_median"] >= rf["kernel_ms_per_launch"] - 1e-6
+        assert 0 < pl["frac_placement_median"] <= rf["frac"] + 1e-6
 
 
 def test_two_ranks_on_one_device_over_rccl_end_with_a_diagnosis_not_a_hang():

@@ -103,3 +103,38 @@ def test_ranks_of_one_scheduler_job_agree_without_a_common_parent(pkg):
     assert c != d                                  # hand-started ranks: no common parent, no job id -> need AMT_RENDEZVOUS_NONCE
     e, f = via_own_shell({"AMT_RENDEZVOUS_NONCE": "x"}), via_own_shell({"AMT_RENDEZVOUS_NONCE": "x"})
     assert e == f
+
+
+def test_two_launches_inside_one_scheduler_job_do_not_share_a_nonce(pkg):
+    """with a scheduler job id set, two torchrun launches inside the one allocation (or an elastic
+    restart on the same port) must still get different nonces -- otherwise ranks >= 1 of the second launch accept the
+    rendezvous file a crashed first launch left.  The local launcher (TORCHELASTIC_RUN_ID set) contributes its run id,
+    its restart count and itself as the parent process; ranks of ONE such launch (one parent) still agree."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as g; "
+            "print(g.load_package().load_library().amt_comm_launch_nonce())" % str(root))
+    base = {k: v for k, v in os.environ.items()
+            if k not in ("AMT_RENDEZVOUS_NONCE", "SLURM_JOB_ID", "SLURM_STEP_ID", "PMI_JOBID", "PMIX_NAMESPACE",
+                         "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "LSB_JOBID", "PBS_JOBID", "PMI_ID_JOB",
+                         "OMPI_MCA_ess_base_jobid")}
+
+    def launch(extra, ranks=1):
+        """One 'launcher' shell that starts `ranks` rank processes: they share the parent."""
+        env = dict(base, **extra)
+        cmd = "; ".join([f"{sys.executable} -c \"{code}\""] * ranks) + "; true"
+        r = subprocess.run(["sh", "-c", cmd], env=env, capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stderr[-500:]
+        return [int(x) for x in r.stdout.split()]
+
+    job = {"SLURM_JOB_ID": "4711", "MASTER_PORT": "29500", "TORCHELASTIC_RUN_ID": "none", "TORCHELASTIC_RESTART_COUNT": "0"}
+    first = launch(job, ranks=2)
+    assert first[0] == first[1] != 0                                     # the ranks of one launch agree
+    assert launch(job)[0] != first[0]                                    # the same command again: another launcher process
+    assert launch(dict(job, TORCHELASTIC_RESTART_COUNT="1"))[0] != first[0]
+    # without a local launcher the scheduler's ids alone decide (one daemon per node: no common parent to mix in)
+    bare = {"SLURM_JOB_ID": "4711", "MASTER_PORT": "29500"}
+    assert launch(bare)[0] == launch(bare)[0]

@@ -115,29 +115,24 @@ uint64_t amt_fnv1a(uint64_t h, const void *data, size_t n)
 // A value every process of ONE launch computes identically and two launches do not share:
 // AMT_RENDEZVOUS_NONCE if set; else a job id the scheduler gives every rank of the job (SLURM_JOB_ID +
 // step, PMI / PMIx / Open MPI job ids, LSB_JOBID, PBS_JOBID) -- such ranks need not share a parent
-// process (one srun / orted daemon per node); else the launcher's run id (TORCHELASTIC_RUN_ID + restart
-// count) and the parent process (pid and start time from /proc: the ranks of a local launch are children of
-// one launcher) together with MASTER_PORT.  Ranks started by hand (a shell or ssh per rank) have neither a job
-// id nor a common parent: they must be given AMT_RENDEZVOUS_NONCE.  Never 0.
+// process (one srun / orted daemon per node) -- together with MASTER_PORT; else the parent process (pid and
+// start time from /proc: the ranks of a local launch are children of one launcher) together with MASTER_PORT.
+// A LOCAL launcher inside either (TORCHELASTIC_RUN_ID is set: torchrun started the ranks of this node) adds
+// its run id, its restart count and itself as the parent process: two torchrun launches inside one
+// allocation, or an elastic restart on the same port, then differ although the scheduler's ids do not
+// (without that, ranks >= 1 of the second launch accepted the file a crashed first one left).
+// Ranks started by hand (a shell or ssh per rank) have neither a job id nor a common parent, and ranks of
+// several torchrun agents that share the rendezvous file over a network file system have different parents:
+// both must be given AMT_RENDEZVOUS_NONCE.  Never 0.
 extern "C" uint64_t amt_comm_launch_nonce(void)
 {
     uint64_t h = 1469598103934665603ull;
     static const char *const job_ids[] = {"SLURM_JOB_ID", "SLURM_STEP_ID", "PMI_JOBID", "PMI_ID_JOB", "PMIX_NAMESPACE",
                                           "OMPI_MCA_ess_base_jobid", "LSB_JOBID", "PBS_JOBID"};
-    bool have_job = false;
-    for (const char *name : job_ids)
-        if (const char *t = getenv(name); t && *t) have_job = true;
-    if (const char *s = getenv("AMT_RENDEZVOUS_NONCE"); s && *s) {
-        h = amt_fnv1a(h, s, strlen(s));
-    } else if (have_job) {
-        for (const char *name : job_ids)
-            if (const char *t = getenv(name); t && *t) { h = amt_fnv1a(h, name, strlen(name)); h = amt_fnv1a(h, t, strlen(t)); }
-        if (const char *t = getenv("MASTER_PORT"); t && *t) h = amt_fnv1a(h, t, strlen(t));
-    } else {
-        // the launcher's run id alone may be a fixed word ("none" for a static rendezvous): always
-        // mix in the parent process as well
-        if (const char *t = getenv("TORCHELASTIC_RUN_ID"); t && *t) h = amt_fnv1a(h, t, strlen(t));
-        if (const char *t = getenv("TORCHELASTIC_RESTART_COUNT"); t && *t) h = amt_fnv1a(h, t, strlen(t));
+    auto mix_env = [&](const char *name) {
+        if (const char *t = getenv(name); t && *t) { h = amt_fnv1a(h, name, strlen(name)); h = amt_fnv1a(h, t, strlen(t)); }
+    };
+    auto mix_parent = [&] {
         const long ppid = (long)getppid();
         h = amt_fnv1a(h, &ppid, sizeof ppid);
         char statpath[64];
@@ -157,8 +152,26 @@ extern "C" uint64_t amt_comm_launch_nonce(void)
                 h = amt_fnv1a(h, q, (size_t)(e - q));
             }
         }
-        if (const char *t = getenv("MASTER_PORT"); t && *t) h = amt_fnv1a(h, t, strlen(t));
+    };
+    bool have_job = false;
+    for (const char *name : job_ids)
+        if (const char *t = getenv(name); t && *t) have_job = true;
+    const char *elastic = getenv("TORCHELASTIC_RUN_ID");
+    const bool local_launcher = elastic && *elastic;
+    if (const char *s = getenv("AMT_RENDEZVOUS_NONCE"); s && *s) {
+        h = amt_fnv1a(h, s, strlen(s));
+        return h ? h : 1;
     }
+    if (have_job)
+        for (const char *name : job_ids) mix_env(name);
+    if (local_launcher) {
+        mix_env("TORCHELASTIC_RUN_ID");
+        mix_env("TORCHELASTIC_RESTART_COUNT");
+    }
+    // the launcher's run id alone may be a fixed word ("none" for a static rendezvous): the parent process as well,
+    // unless the scheduler's ids are all there is to agree on (its ranks have one daemon per node as parents)
+    if (!have_job || local_launcher) mix_parent();
+    mix_env("MASTER_PORT");
     return h ? h : 1;
 }
 
