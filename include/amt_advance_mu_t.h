@@ -342,11 +342,6 @@ int amt_calib_stream_rate(void *hip_stream, void *dst_device, const void *src_de
  *     launcher can choose unforced, one per line (returns the bytes needed).
  * ------------------------------------------------------------------------ */
 int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, int jrows, int max_waves);
-/* The block schedule of launches that run for several rounds of workgroups: 0 (default) = uniform blocks,
- * 1 = tapered by the launcher's rule (one segment of rows per XCD, blocks of decreasing length), n > 1 = tapered
- * with blocks of at most n rows.  An experiment kept for A/B runs: measured 0.2-2.5 % slower than uniform
- * blocks (profiles/r03_block_schedule.md).  Also AMT_MARCH_TAPER. */
-int amt_march_set_taper(int taper);
 const char *amt_march_last_kernel(void);
 int amt_march_selectable(char *buf, int cap);
 

@@ -16,13 +16,14 @@
 !   * the omega recurrence (:159-163), its perturbation form (:168-172) and the vertical theta flux
 !     (:224-229) are ONE k loop: ww is written once and never read back (the un-subtracted value of the
 !     level below is carried in a per-column scalar, exactly the value the reference reads from ww(k-1));
-!   * the k-column scratch lives on the calling thread's stack (the reference's (its:ite,kts:kte)
-!     automatics are 2 x 2 MB at 4096 columns);
+!   * the k-column scratch is one block wide and belongs to the calling thread (the reference's
+!     (its:ite,kts:kte) automatics are 2 x 2 MB at 4096 columns);
 !   * no debug dumps (:175-189 are a side effect of the sample, 99.6 % of its wall time);
 !   * OpenMP over j-tiles in the C-callable drivers below: every thread calls the routine with its own
 !     jts:jte, the scheme sketched in the reference driver (advance_mu_t_driver.f90:175-209).
 !
-! Build knobs (-cpp): AMT_IB columns per i block (default 256), AMT_J_OUTER=1 the r03 loop order (A/B only).
+! Build knobs (-cpp): AMT_IB columns per i block (default 1024: the fastest of 64 ... 4096 on 16 cores of 2 x EPYC 9575F,
+! profiles/r04_cpu_fortran_tune.txt), AMT_J_OUTER=1 the r03 loop order (A/B only).
 !
 ! Every expression keeps the reference's association and the file is compiled with
 ! -ffp-contract=off, so the results are the reference's bits: tests/test_fortran_cpu.py holds it
@@ -35,7 +36,7 @@ module advance_mu_t_cpu_mod
   private
   public :: advance_mu_t_cpu
 #ifndef AMT_IB
-#define AMT_IB 256
+#define AMT_IB 1024
 #endif
   integer, parameter :: IB = AMT_IB       ! columns per i block (scratch: 2 x IB x kde reals)
 
@@ -65,13 +66,22 @@ contains
     real, dimension(kms:kme), intent(in) :: fnm, fnp, dnw, rdnw
     real, intent(in) :: rdx, rdy, dts, epssm
 
-    real :: div(IB, kts:kte)      ! horizontal mass-flux divergence of the block's columns
-    real :: flx(IB, kts:kte+1)    ! vertical theta flux at the level interfaces
+    ! one block wide, kept by the calling thread from call to call (threadprivate: a fresh 1 MB allocation per
+    ! call and thread is an mmap / page-fault / munmap round trip on every sweep)
+    real, allocatable, save :: div(:, :)     ! (IB, kts:kte)   horizontal mass-flux divergence of the block's columns
+    real, allocatable, save :: flx(:, :)     ! (IB, kts:kte+1) vertical theta flux at the level interfaces
+    !$omp threadprivate(div, flx)
     real :: colsum(IB)            ! its column integral
     real :: wwu(IB)               ! omega of the recurrence (:161) at the current level, before :170
     real :: old_mu
     integer :: i, j, k, ib0, ib1, n, ic
     integer :: i_lo, i_hi, j_lo, j_hi, k_hi
+
+    ! on the heap: 2 x IB x kde reals would not fit an OpenMP worker's stack at a few hundred levels
+    if (allocated(div)) then
+      if (lbound(div, 2) /= kts .or. ubound(div, 2) /= kte) deallocate(div, flx)
+    end if
+    if (.not. allocated(div)) allocate(div(IB, kts:kte), flx(IB, kts:kte+1))
 
     ! the compute window (reference :91-106)
     i_lo = its

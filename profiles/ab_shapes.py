@@ -35,13 +35,8 @@ abytes = np.dtype(dtype).itemsize * a.ni * a.nj * (11 * a.nk + 14)
 
 
 def setup(spec):
-    L.amt_march_set_taper(0)
     if spec == "auto":
         L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
-        return 0
-    if spec[0] == "t":
-        L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
-        L.amt_march_set_taper(int(spec[1:]))
         return 0
     if spec == "column":
         L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
@@ -72,7 +67,6 @@ for rnd in range(a.rounds):
         torch.cuda.synchronize()
         times[spec].append(e0.elapsed_time(e1) / a.inner)
 L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
-L.amt_march_set_taper(0)
 print(f"# {a.ni}x{a.nk}x{a.nj} {a.dtype} idim {b.idim}: {abytes / 1e9:.2f} GB algorithmic per sweep")
 for spec in a.shapes:
     v = times[spec]

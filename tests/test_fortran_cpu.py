@@ -37,17 +37,18 @@ def test_fortran_cpu_path_matches_reference_full_arrays(pkg, oracle):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_j_tiles_blocks_and_the_native_build_keep_the_bits(pkg, oracle, dtype):
-    """i blocks of 128 columns (300 columns = 2 whole blocks + a ragged one), any number of j tiles, and
-    the -march=native build that bench.py times: all the C oracle's bits."""
-    b = pkg.synth.domain_bounds(300, 17, 23, aligned=True)
-    p = pkg.synth.make_patch(b, pkg.GridConfig(nested=True), dtype=dtype, seed=99)
-    want = p.copy()
-    oracle.advance_mu_t(*want.args())
-    for nthreads, native in ((1, False), (4, False), (23, False), (64, False), (3, True)):
-        q = p.copy()
-        oracle.fortran_advance_mu_t(*q.args(), nthreads=nthreads, native=native)
-        for n in pkg.synth.FIELD_NAMES:
-            assert bits_equal(q.arrays[n], want.arrays[n]), (nthreads, native, n)
+    """i blocks of 1024 columns marching in j (2200 columns = 2 whole blocks + a ragged one; 300 = one ragged
+    block), any number of j tiles, and the -march=native build that bench.py times: all the C oracle's bits."""
+    for dims in ((300, 17, 23), (2200, 6, 9)):
+        b = pkg.synth.domain_bounds(*dims, aligned=True)
+        p = pkg.synth.make_patch(b, pkg.GridConfig(nested=True), dtype=dtype, seed=99)
+        want = p.copy()
+        oracle.advance_mu_t(*want.args())
+        for nthreads, native in ((1, False), (4, False), (23, False), (64, False), (3, True)):
+            q = p.copy()
+            oracle.fortran_advance_mu_t(*q.args(), nthreads=nthreads, native=native)
+            for n in pkg.synth.FIELD_NAMES:
+                assert bits_equal(q.arrays[n], want.arrays[n]), (dims, nthreads, native, n)
 
 
 def test_fortran_cpu_path_refuses_undefined_bounds(pkg, oracle):

@@ -106,33 +106,3 @@ def test_forced_shape_that_cannot_run_fails_loudly(pkg, force):
     with pytest.raises(pkg.AmtError):
         pkg.advance_mu_t(*dev.args(), variant=pkg.VARIANT_MARCH)
     torch.cuda.synchronize()
-
-
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("taper", [1, 8, 16, 48])
-def test_tapered_block_schedule_matches_oracle(pkg, oracle, dtype, taper):
-    """The opt-in tapered schedule (amt_march_set_taper / AMT_MARCH_TAPER: one segment of rows per XCD, blocks of
-    decreasing length; measured slower than uniform blocks and off by default, profiles/r03_block_schedule.md) stays
-    a correct way to run the sweep: row counts that split evenly over the eight segments and ones that leave the last
-    segment short or empty, all flag combinations, against the oracle and with the launcher's label saying so."""
-    import torch
-    L = pkg.load_library()
-    S = pkg.synth
-    try:
-        for nj, flags in ((128, dict()), (131, dict(specified=True)), (200, dict(nested=True)), (17, dict(specified=True, periodic_x=True))):
-            b = S.domain_bounds(150, 9, nj, aligned=bool(nj % 2))
-            host = S.make_patch(b, pkg.GridConfig(**flags), dtype=dtype, seed=300 + nj)
-            want = host.copy()
-            oracle.advance_mu_t(*want.args())
-            L.amt_march_set_taper(taper)
-            dev = host.to_device("cuda:0")
-            pkg.advance_mu_t(*dev.args(), variant=pkg.VARIANT_MARCH)
-            torch.cuda.synchronize()
-            label = L.amt_march_last_kernel().decode()
-            got = dev.to_host()
-            for n in S.FIELD_NAMES:
-                assert bits_equal(got.arrays[n], want.arrays[n]), f"taper {taper}, {nj} rows: {n} ({label})"
-            if taper > 1 and nj >= 128:
-                assert "tapered 8 x [" in label, label
-    finally:
-        L.amt_march_set_taper(0)

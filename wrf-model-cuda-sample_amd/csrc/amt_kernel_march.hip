@@ -83,35 +83,9 @@ static int amt_env_int(const char *name, int dflt)
 #ifndef AMT_NT_DMA
 #define AMT_NT_DMA 0    /* cache-policy bits of the bulk LDS-DMA loads (2 = nt) */
 #endif
-// Measured alternatives kept as build switches (profiles/r02_shapes.md; A/B by build with profiles/ab_libs.py):
-#ifndef AMT_U_FROM_LANE
-#define AMT_U_FROM_LANE 0   /* DMA flavour: u, u_1 at column + 1 by a DPP lane shift instead of a second load: two global
-                               loads per level fewer, but ~30 more VGPRs in hipcc's schedule and 15 % slower */
-#endif
-#ifndef AMT_D2_REREAD
-#define AMT_D2_REREAD 0     /* 1: muu, msfuy of a level re-read from LDS per level instead of held across the levels:
-                               saves 8 VGPRs in fp64, costs 1.7 % at 4096x60x4096 */
-#endif
-#ifndef AMT_CARRY_ROW2D
-#define AMT_CARRY_ROW2D 0   /* 1: msfty, mu_tend carried in registers from P1 to P3 instead of re-read from LDS: +4 VGPRs
-                               in fp64, no gain */
-#endif
 #ifndef AMT_CHAIN
 #define AMT_CHAIN 10    /* LDS reads kept in flight by the sequential k chains */
 #endif
-// PRICING builds only (wrong results; profiles/r03_column_wave_pricing.md): what would a schedule be worth that
-// halves the column wave's chain time per row (two rows' chains side by side on the 64 lanes) or the number of
-// barriers per row?  AMT_DIAG_CHAIN_DIV n: both k chains run over nk / n levels.  AMT_DIAG_FEWER_BARRIERS 1:
-// barriers 2 and 3 (the LDS-only ones) are dropped in every wave.
-#ifndef AMT_DIAG_CHAIN_DIV
-#define AMT_DIAG_CHAIN_DIV 1
-#endif
-#ifndef AMT_DIAG_FEWER_BARRIERS
-#define AMT_DIAG_FEWER_BARRIERS 0
-#endif
-
-constexpr int AMT_MAX_SCHED = 30;      // most blocks of one segment of a tapered schedule
-
 struct AmtMarchGrid {
     int ntile_i;     // number of i tiles that hold window columns
     int col_lo;      // memory column of the first tile's column 0: the window's first column rounded down to a 128-B line
@@ -119,16 +93,6 @@ struct AmtMarchGrid {
     int jstep;       // rows from one j block's first row to the next one's (jrows; edge launches: j1 - j0)
     int njblk;       // number of j blocks
     int nwg;         // ntile_i * njblk
-    // Tapered schedule (nseg = 8; opt-in, AMT_MARCH_TAPER / amt_march_set_taper): the window's rows are cut
-    // into one segment per XCD (seg_rows each), and every segment into nb blocks whose lengths DEcrease -- block
-    // b of a segment covers rows joff[b] .. joff[b+1]-1 of it.  Workgroups are dispatched in blockIdx order, so
-    // the long blocks start first and the short ones fill in at the end: meant to shorten the launch's tail.
-    // MEASURED (profiles/r03_block_schedule.md): 0.2 .. 2.5 % SLOWER than uniform 64-row blocks at every size
-    // from 4096x60x512 to 4096x60x4096 in both precisions -- the launch's fixed cost (about 0.3 ms) is not a
-    // tail of unevenly finishing workgroups -- so it is off by default and kept as the experiment it was.
-    // nseg = 0: uniform blocks of jrows rows.
-    int nseg, seg_rows, nb;
-    unsigned short joff[AMT_MAX_SCHED + 1];
 };
 
 // ---------------------------------------------------------------------------
@@ -260,28 +224,28 @@ template <typename T, int VW> __device__ __forceinline__ void amt_stsv(T *q, con
     for (int e = 0; e < VW; ++e) q[e] = v.x[e];
 }
 
-// x of lane + 1 (DPP wave shift: one VALU move per dword, no LDS, no memory).  Lane 63 keeps its own x.
-// Every lane whose neighbour's value is consumed must be active together with that neighbour.
-__device__ __forceinline__ float amt_lane_above(float x)
+#ifndef AMT_STAMPS
+#define AMT_STAMPS 0    /* 1: instrumentation build (profiles/stamps.py): the middle workgroup records s_memtime at the phase
+                           boundaries of rows 4..35 of its block -- first cell wave, last cell wave, column wave */
+#endif
+#if AMT_STAMPS
+__device__ unsigned long long amt_stamp_buf[3][32][8];
+#define AMT_STAMP(slot, n) do { if (stamp_on && jj - ja >= 4 && jj - ja < 36) { unsigned long long t_;                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                                  \
+        if (lane == 0) amt_stamp_buf[slot][jj - ja - 4][n] = t_; } } while (0)
+extern "C" int amt_diag_stamps(void *out, int bytes)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(amt_stamp_buf), (size_t)bytes < sizeof amt_stamp_buf ? (size_t)bytes : sizeof amt_stamp_buf);
 }
-__device__ __forceinline__ double amt_lane_above(double x)
-{
-    const int lo = __double2loint(x), hi = __double2hiint(x);
-    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false),
-                            __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false));
-}
+#else
+#define AMT_STAMP(slot, n) do { } while (0)
+#endif
 
 constexpr int AMT_N2D = 7;    // staged 2-D rows: msftx msfty muu msfuy muv' msfvx_inv' mu_tend
 
 __device__ __forceinline__ void amt_lds_barrier()
 {
-#if AMT_DIAG_FEWER_BARRIERS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 
@@ -341,30 +305,20 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
     // dispatch), so give each XCD a contiguous run of logical ids: neighbouring i-tiles
     // of one j block then run on one XCD at about the same time and share the tile-edge
     // cache lines in that XCD's L2.  Speed only, never correctness.
-    int lid, ja, jb;
-    if (g.nseg) {
-        // tapered schedule: XCD x = blockIdx % 8 owns segment x; its workgroups come in the order of y
-        const int x = blockIdx.x % 8, y = blockIdx.x / 8;
-        const int blk = y / g.ntile_i;
-        lid = y % g.ntile_i;                      // the tile
-        ja = p.j0 + x * g.seg_rows + g.joff[blk];
-        jb = p.j0 + x * g.seg_rows + g.joff[blk + 1] - 1;
-        const int jlast = (x + 1) * g.seg_rows - 1 < p.j1 - p.j0 ? p.j0 + (x + 1) * g.seg_rows - 1 : p.j1;
-        if (jb > jlast) jb = jlast;
-        if (ja > jb) return;                      // the last segment may be short (before any barrier: the whole workgroup leaves)
-    } else {
-        const int nx = 8, q = g.nwg / nx, r = g.nwg % nx;
-        const int x = blockIdx.x % nx, y = blockIdx.x / nx;
-        lid = x * q + (x < r ? x : r) + y;        // XCD x owns q (+1 if x < r) consecutive ids
-        const int jblk = lid / g.ntile_i;
-        ja = p.j0 + jblk * g.jstep;
-        jb = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
-    }
+    const int nx = 8, q = g.nwg / nx, r = g.nwg % nx;
+    const int x = blockIdx.x % nx, y = blockIdx.x / nx;
+    const int lid = x * q + (x < r ? x : r) + y;      // XCD x owns q (+1 if x < r) consecutive ids
+    const int ja = p.j0 + (lid / g.ntile_i) * g.jstep;
+    const int jb = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
     // Tiles are anchored at the WINDOW (its first column rounded down to a 128-byte line of the row), not
     // at multiples of TC from the row start: a window that starts 32 elements into a row (the resident
     // layout) would otherwise straddle one more, half-empty tile (512x60x512: 9 x 27 = 243 workgroups on
     // 256 CUs instead of 8 x 32).  Neither the LDS-DMA nor the plain loads need more than line alignment.
     const int col0 = g.col_lo + (lid % g.ntile_i) * TC;
+#if AMT_STAMPS
+    const bool stamp_on = (lid == g.nwg / 2 + g.ntile_i / 2) && (w == 0 || w >= nc - 1);
+    const int stamp_slot = w == 0 ? 0 : colw ? 2 : 1;
+#endif
 
     for (int e = threadIdx.x; e < 4 * nkr; e += blockDim.x) {
         const int which = e & 3, k = e >> 2;
@@ -430,6 +384,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         unsigned o3 = vo, o2 = vo;
         for (int jj = ja; jj <= jb; ++jj, o3 += row3, o2 += row2) {
             const bool more = (jj < jb);
+            AMT_STAMP(2, 0);
             // while the cell waves do P1: fetch the next 2-D row and this row's column inputs
             V d2v[N2D];
             T d2h[N2D];                                          // lane 0: the right halo; a tail lane: its one column
@@ -451,19 +406,20 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                 mut_v = amt_ldv<T, VW>(mut_b, o2);
             }
             if (own) { mu_tend = amt_ldsv<T, VW>(D2 + 6 * TW + c); msfty_c = amt_ldsv<T, VW>(D2 + 1 * TW + c); }
+            AMT_STAMP(2, 1);
             __syncthreads();                                     // 1: AB complete, D2/T1 row j no longer read
+            AMT_STAMP(2, 2);
             V dmdt(T(0));
-            const int nkc = nk / AMT_DIAG_CHAIN_DIV;             // = nk in every product build
             if (own) {                                           // :147, sequential in k
                 int k = 0;
-                for (; k + AMT_CHAIN <= nkc; k += AMT_CHAIN) {
+                for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
                     V a[AMT_CHAIN];
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) a[q] = s_dnw(k + q) * amt_ldsv<T, VW>(AB + (k + q) * TC + c);
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) dmdt = dmdt + a[q];
                 }
-                for (; k < nkc; ++k) dmdt = dmdt + s_dnw(k) * amt_ldsv<T, VW>(AB + k * TC + c);
+                for (; k < nk; ++k) dmdt = dmdt + s_dnw(k) * amt_ldsv<T, VW>(AB + k * TC + c);
                 // with dmdt: this row's mu_tend and msfty, for the cell waves' P2 and P3 (D2 moves on to
                 // row j+1 below; these stay until the column wave passes barrier 1 of the next row)
                 amt_stsv<T, VW>(DM + c, dmdt);
@@ -478,7 +434,9 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                     if (tail) D2[q * TW + c] = d2h[q];
                 }
             }
+            AMT_STAMP(2, 3);
             amt_lds_barrier();                                   // 2: DM published
+            AMT_STAMP(2, 4);
             if (any) {                                           // :151-157
                 const V mu_new = mu_old + dts * (dmdt + mu_tend);
                 amt_stv<T, VW>(mu_b, o2, mu_new, all, on);
@@ -486,19 +444,22 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                 amt_stv<T, VW>(muts_b, o2, mut_v + mu_new, all, on);
                 amt_stv<T, VW>(muave_b, o2, T(.5) * ((T(1.) + p.epssm) * mu_new + (T(1.) - p.epssm) * mu_old), all, on);
             }
+            AMT_STAMP(2, 5);
             amt_lds_barrier();                                   // 3: AB holds the increments
+            AMT_STAMP(2, 6);
             if (own) {                                           // :161, sequential in k; AB[k] <- ww(k), the value BEFORE increment k
                 V wwu = ww1in;
                 int k = 0;
-                for (; k + AMT_CHAIN <= nkc; k += AMT_CHAIN) {
+                for (; k + AMT_CHAIN <= nk; k += AMT_CHAIN) {
                     V b[AMT_CHAIN];
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) b[q] = amt_ldsv<T, VW>(AB + (k + q) * TC + c);
 #pragma unroll
                     for (int q = 0; q < AMT_CHAIN; ++q) { amt_stsv<T, VW>(AB + (k + q) * TC + c, wwu); wwu = wwu - b[q]; }
                 }
-                for (; k < nkc; ++k) { const V bk = amt_ldsv<T, VW>(AB + k * TC + c); amt_stsv<T, VW>(AB + k * TC + c, wwu); wwu = wwu - bk; }
+                for (; k < nk; ++k) { const V bk = amt_ldsv<T, VW>(AB + k * TC + c); amt_stsv<T, VW>(AB + k * TC + c, wwu); wwu = wwu - bk; }
             }
+            AMT_STAMP(2, 7);
             __syncthreads();                                     // 4: ww of the recurrence published (DMA landed)
         }
     } else {
@@ -635,8 +596,8 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             dma_rows(ln, v_b, r + 1, VB);                                        // v(j+1)
             dma_halo(ln, t1_b, r + 1, thdst);
             if (XD >= 1) dma_rows(ln, v1_b, r + 1, V1);                          // v_1(j+1)
-            if (XD >= 2 || AMT_U_FROM_LANE) dma_uhalo(ln, u_b, r, UH);           // u, u_1 at column TC of row j
-            if (XD >= 3 || AMT_U_FROM_LANE) dma_uhalo(ln, u1_b, r, UH + nkr);
+            if (XD >= 2) dma_uhalo(ln, u_b, r, UH);                              // u, u_1 at column TC of row j
+            if (XD >= 3) dma_uhalo(ln, u1_b, r, UH + nkr);
             if (XD >= 2) dma_rows(ln, u_b, r, U);                                // u(j)
             if (XD >= 3) dma_rows(ln, u1_b, r, U1);
         };
@@ -683,19 +644,15 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
         unsigned o3 = vo + hoff;                       // per-lane byte offset of the current row
         for (int jj = ja; jj <= jb; ++jj, o3 += row3) {
             V hf[KPT], tw[KPT];
-            V msfty_c(T(1)), mu_tend_c(T(0));
             const int par = (jj - ja) & 1;
             const T *T1c = T1 + par * t1buf;                         // t_1 row j
             T *T1n = T1 + (par ^ 1) * t1buf;                         // t_1 row j+1 (DMA'd during the previous row / written now)
             const T *THc = TH + par * thbuf;
             T *THn = TH + (par ^ 1) * thbuf;
             const bool more = (jj < jb);
+            AMT_STAMP(stamp_slot, 0);
 
             // ---------------- P1: per-cell work from pure inputs ----------------
-            // With AMT_U_FROM_LANE every lane inside the memory row runs P1, window column or not (they
-            // differ in the two edge tiles only): u and u_1 at a lane's last column + 1 then come from the
-            // NEXT LANE's registers (amt_lane_above), so that lane must be executing.  What the lanes
-            // outside the window compute is never stored.
             if (!DMA) {
                 reg_halo(t1_b + js, o3 - vo - hoff, THn);                      // i halo of t_1 row j+1
                 if (inmem && !act) {                                 // columns of the tile outside the window
@@ -704,16 +661,12 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                         amt_stsv<T, VW>(T1n + (kfw + m) * TC + lc, amt_ldv<T, VW>(t1_b + js, o3 + lo(m)));
                 }
             }
-            if ((AMT_U_FROM_LANE && DMA) ? inmem : act) {
+            if (act) {
                 const V msftx = amt_ldsv<T, VW>(D2 + 0 * TW + c);
                 const V msfty_p1 = amt_ldsv<T, VW>(D2 + 1 * TW + c);
                 const V mm = msftx * msfty_p1;
-                if (AMT_CARRY_ROW2D) { msfty_c = msfty_p1; mu_tend_c = amt_ldsv<T, VW>(D2 + 6 * TW + c); }
-                V muu_i0, muu_ip0, msfuy_i0, msfuy_ip0;
-                if (!AMT_D2_REREAD) {
-                    muu_i0 = amt_ldsv<T, VW>(D2 + 2 * TW + c); muu_ip0 = amt_ldsv<T, VW>(D2 + 2 * TW + c + 1);
-                    msfuy_i0 = amt_ldsv<T, VW>(D2 + 3 * TW + c); msfuy_ip0 = amt_ldsv<T, VW>(D2 + 3 * TW + c + 1);
-                }
+                const V muu_i = amt_ldsv<T, VW>(D2 + 2 * TW + c), muu_ip = amt_ldsv<T, VW>(D2 + 2 * TW + c + 1);
+                const V msfuy_i = amt_ldsv<T, VW>(D2 + 3 * TW + c), msfuy_ip = amt_ldsv<T, VW>(D2 + 3 * TW + c + 1);
                 const V muv_p = amt_ldsv<T, VW>(D2 + 4 * TW + c), mvx_p = amt_ldsv<T, VW>(D2 + 5 * TW + c);
                 // Neighbour columns c-1 and c+VW are read unclamped: for the tile's first / last lane they
                 // fall into the adjacent LDS row (always inside the LDS image) and the halo value is
@@ -724,15 +677,6 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                     const int K = kf + m;
                     V vn, v1n, t1n, uu, u1;
                     T un, u1n;                                               // u, u_1 at my last column + 1
-                    // muu, msfuy at i and i+1: re-read per level through a laundered address (8 registers
-                    // in fp64 that the level loop needs more than these four LDS reads cost)
-                    V muu_i, muu_ip, msfuy_i, msfuy_ip;
-                    if (AMT_D2_REREAD) {
-                        const T *d2m = D2 + 2 * TW + c;
-                        asm volatile("" : "+v"(d2m));
-                        muu_i = amt_ldsv<T, VW>(d2m); muu_ip = amt_ldsv<T, VW>(d2m + 1);
-                        msfuy_i = amt_ldsv<T, VW>(d2m + TW); msfuy_ip = amt_ldsv<T, VW>(d2m + TW + 1);
-                    } else { muu_i = muu_i0; muu_ip = muu_ip0; msfuy_i = msfuy_i0; msfuy_ip = msfuy_ip0; }
                     if (DMA) { vn = amt_ldsv<T, VW>(VB + (kfw + m) * TC + lc); t1n = amt_ldsv<T, VW>(T1n + (kfw + m) * TC + lc); }
                     else {
                         vn = amt_ldv<T, VW>(v_b + js, om); t1n = amt_ldv<T, VW>(t1_b + js, om);
@@ -743,19 +687,11 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                         uu = amt_ldsv<T, VW>(U + (kfw + m) * TC + lc);
                         const T in = U[(kfw + m) * TC + lc + VW];
                         un = (il == TI - 1) ? UH[kfw + m + lh] : in;
-                    } else if (AMT_U_FROM_LANE && DMA) {
-                        uu = amt_ldv_stream<2, T, VW>(u_b, om);
-                        const T nb = amt_lane_above(uu.x[0]);
-                        un = (il == TI - 1) ? UH[kfw + m + lh] : nb;
                     } else { uu = amt_ldv_stream<2, T, VW>(u_b, om); un = amt_ld_stream<2>(u_b + VW, om); }
                     if (XD >= 3) {
                         u1 = amt_ldsv<T, VW>(U1 + (kfw + m) * TC + lc);
                         const T in = U1[(kfw + m) * TC + lc + VW];
                         u1n = (il == TI - 1) ? UH[nkr + kfw + m + lh] : in;
-                    } else if (AMT_U_FROM_LANE && DMA) {
-                        u1 = amt_ldv_stream<2, T, VW>(u1_b, om);
-                        const T nb = amt_lane_above(u1.x[0]);
-                        u1n = (il == TI - 1) ? UH[nkr + kfw + m + lh] : nb;
                     } else { u1 = amt_ldv_stream<2, T, VW>(u1_b, om); u1n = amt_ld_stream<2>(u1_b + VW, om); }
                     const V t1c = amt_ldsv<T, VW>(T1c + (kfw + m) * TC + lc);
                     const T tl_in = (T1c + (kfw + m) * TC + lc)[-1], tr_in = T1c[(kfw + m) * TC + lc + VW];
@@ -789,7 +725,9 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                 // parities: the group above may be a row ahead by then)
                 amt_stsv<T, VW>(TWB + (par * nc * HL + w * HL) * TC + lane * VW, tw[0]);   // [group w*HL+h][column c] = lane*VW
             }
+            AMT_STAMP(stamp_slot, 1);
             __syncthreads();                                         // 1: AB complete; row j of T1/TH/VB/D2 dead
+            AMT_STAMP(stamp_slot, 2);
 
             if (DMA && more) {   // what the next row's P1 needs: no registers, lands before barrier 4
                 int ln = lane;
@@ -810,12 +748,14 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                     w1[m] = amt_ldv_stream<1, T, VW>(ww1_b, om);
                 }
             }
+            AMT_STAMP(stamp_slot, 3);
             amt_lds_barrier();                                       // 2: DM published (DMA keeps flying)
+            AMT_STAMP(stamp_slot, 4);
             V inc_last(T(0));                                       // my top level's increment (:161)
             if (act) {
                 const V dmdt = amt_ldsv<T, VW>(DM + c);
-                const V mu_tend = AMT_CARRY_ROW2D ? mu_tend_c : amt_ldsv<T, VW>(DM + TC + c);
-                const V msfty = AMT_CARRY_ROW2D ? msfty_c : amt_ldsv<T, VW>(DM + 2 * TC + c);
+                const V mu_tend = amt_ldsv<T, VW>(DM + TC + c);
+                const V msfty = amt_ldsv<T, VW>(DM + 2 * TC + c);
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
                     const V inc = S1[4 * (kfw + m) + 4 * lh] * (dmdt + amt_ldsv<T, VW>(AB + (kfw + m) * TC + lc) + mu_tend) / msfty;   // :161
@@ -823,12 +763,14 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                     if (m == KPT - 1) inc_last = inc;
                 }
             }
+            AMT_STAMP(stamp_slot, 5);
             amt_lds_barrier();                                       // 3: AB holds the increments
             __syncthreads();                                         // 4: ww of the recurrence published; DMA landed
+            AMT_STAMP(stamp_slot, 6);
 
             // ---------------- P3: vertical flux, theta ----------------
             if (act) {
-                const V msfty = AMT_CARRY_ROW2D ? msfty_c : amt_ldsv<T, VW>(DM + 2 * TC + c);
+                const V msfty = amt_ldsv<T, VW>(DM + 2 * TC + c);
                 V wwu = amt_ldsv<T, VW>(AB + kfw * TC + lc);           // ww of :161 at my first level
                 V wd_k = (kf == 0) ? V(T(0)) : (wwu - w1[0]) * tw[0];   // wdtn(i,1) = 0 (:220)
 #pragma unroll
@@ -854,6 +796,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                     wwu = wwu_n; wd_k = wd_n;
                 }
             }
+            AMT_STAMP(stamp_slot, 7);
             // No barrier here.  What the next row's P1 writes (its own AB slots, and -- register
             // flavour -- the T1/TH buffer that was READ in this row's P1) is read by no other wave
             // before barrier 1 of the next row.
@@ -889,11 +832,14 @@ static int amt_march_waves(const AmtMarchShape &s, int nk)
 // of its global SOURCE (measured on gfx950: sources shifted by 4, 8 or 12 bytes copy correctly and at
 // the aligned rate, 6.1-6.2 TB/s; profiles/r02_lds_dma_alignment.md), so any WRF layout -- odd row
 // lengths, arrays that start anywhere -- takes it.  A chunk that starts inside the memory row but runs
-// past its end reads on into the next level row of the same array (the levels fetched end below
-// kme >= kte, so there always is one) and fills LDS columns no lane uses.
-template <typename T> static bool amt_march_dma_layout_ok(const AmtParams<T> &)
+// past its end (tiles anchored at an odd window column, or a row length that is no multiple of a chunk)
+// reads on into the next level row of the same array and fills LDS columns no lane uses: the last level
+// the DMA fetches is the window's last one, so the array must hold one more level row behind it
+// (kme > k_end, which the C-ABI's precondition kme >= kte = k_end + 1 gives every caller; checked here
+// because the kernel's safety rests on it), otherwise the register flavour runs.
+template <typename T> static bool amt_march_dma_layout_ok(const AmtParams<T> &p)
 {
-    return true;
+    return p.k1 + p.nk < p.kdim;
 }
 
 static bool amt_march_shape_valid(int wbytes, const AmtMarchShape &s)
@@ -1007,9 +953,8 @@ template <typename T> static AmtMarchEntry<T> *amt_march_find(const AmtMarchShap
 // that walk every instantiation; 0 / -1 leave a parameter to the launcher.
 struct AmtMarchEnv {
     int dma, kpt, hl, vw, xd, jrows, verbose, wm;
-    int taper;       // tapered block schedule (an experiment that lost): 0 off (default), 1 the rule, > 1 the longest block in rows
 };
-static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 0};
+static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0};
 // The instantiation the last plan of the calling thread chose (diagnosis / tests): "" before any launch.
 static thread_local char g_march_last[360] = "";
 extern "C" const char *amt_march_last_kernel(void) { return g_march_last; }
@@ -1022,8 +967,7 @@ static const AmtMarchEnv &amt_march_env()
         g_march_env = {amt_env_int("AMT_MARCH_DMA", 1), amt_env_int("AMT_MARCH_KPT", 0),
                        amt_env_int("AMT_MARCH_HL", 0), amt_env_int("AMT_MARCH_VW", 0),
                        amt_env_int("AMT_MARCH_XD", -1), amt_env_int("AMT_MARCH_JROWS", 0),
-                       amt_env_int("AMT_MARCH_VERBOSE", 0), amt_env_int("AMT_MARCH_WM", 0),
-                       amt_env_int("AMT_MARCH_TAPER", 0)};
+                       amt_env_int("AMT_MARCH_VERBOSE", 0), amt_env_int("AMT_MARCH_WM", 0)};
     });
     return g_march_env;
 }
@@ -1040,38 +984,6 @@ extern "C" int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, i
     g_march_env.wm = wm > 0 ? wm : 0;
     ++g_march_generation;
     return 0;
-}
-
-extern "C" int amt_march_set_taper(int taper)
-{
-    (void)amt_march_env();
-    g_march_env.taper = taper < 0 ? 0 : taper;
-    ++g_march_generation;
-    return 0;
-}
-
-// Tapered schedule of one segment of `seg` rows: main blocks of about lmax rows, then halving ones down to
-// lmin.  Returns the number of blocks (0: does not fit AMT_MAX_SCHED); joff[0..nb] are the block starts.
-static int amt_march_taper(int seg, int lmax, int lmin, unsigned short *joff)
-{
-    int tail[16], nt = 0, tsum = 0;
-    if (lmax > seg) lmax = seg;
-    if (lmin > lmax) lmin = lmax;
-    for (int t = lmax / 2; t >= lmin && nt < 14; t /= 2) { tail[nt++] = t; tsum += t; }
-    if (nt && tsum + lmin <= seg) { tail[nt++] = lmin; tsum += lmin; }
-    while (nt && tsum > seg) tsum -= tail[--nt];                    // (cannot happen: tsum <= lmax <= seg)
-    int mainrows = seg - tsum;
-    if (nt && mainrows > 0 && mainrows < lmin) { tail[0] += mainrows; mainrows = 0; }   // no sliver of a first block
-    const int nmain = mainrows > 0 ? (mainrows + lmax - 1) / lmax : 0;
-    if (nmain + nt > AMT_MAX_SCHED || nmain + nt < 1) return 0;
-    int nb = 0, at = 0;
-    for (int b = 0; b < nmain; ++b) {
-        joff[nb++] = (unsigned short)at;
-        at += mainrows / nmain + (b < mainrows % nmain ? 1 : 0);
-    }
-    for (int b = 0; b < nt; ++b) { joff[nb++] = (unsigned short)at; at += tail[b]; }
-    joff[nb] = (unsigned short)at;                                  // = seg
-    return nb;
 }
 
 // Rows per workgroup.  A block costs its rows plus a prologue (4 extra array-rows of loads, about
@@ -1272,26 +1184,6 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
         g.njblk = 2;
     }
     g.nwg = g.ntile_i * g.njblk;
-    g.nseg = 0; g.seg_rows = 0; g.nb = 0;
-    memset(g.joff, 0, sizeof g.joff);
-    if (!p.edges && env.jrows < 1 && env.taper) {
-        // Launches of several rounds: one segment of rows per XCD, blocks of decreasing length (see AmtMarchGrid).
-        // Worth it when a segment keeps its XCD's compute units busy for at least two rounds of the longest blocks.
-        const int cpx = amt_march_cus(pl.dev) / 8 > 0 ? amt_march_cus(pl.dev) / 8 : 1;
-        const int seg = (nj + 7) / 8;
-        int lmax = env.taper > 1 ? env.taper : 64;
-        if (lmax > max_rows) lmax = (int)max_rows;
-        if (lmax > seg) lmax = seg;
-        const bool enough = env.taper > 1 || (long)g.ntile_i * seg >= 2L * cpx * lmax;
-        if (enough && seg >= 16 && seg < 65536) {
-            const int nb = amt_march_taper(seg, lmax, lmax < 8 ? lmax : 8, g.joff);
-            if (nb > 0) {
-                g.nseg = 8; g.seg_rows = seg; g.nb = nb;
-                g.nwg = 8 * nb * g.ntile_i;
-                g.jrows = lmax;                       // reporting only
-            }
-        }
-    }
     if (pl.lds > 64 * 1024) {
         // the attribute is per device and per kernel instantiation: allow all of the CU's LDS once
         // (what a launch occupies is its own dynamic size, not this ceiling); one-shot calls plan from
@@ -1304,18 +1196,10 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
             pl.entry->lds_granted[pl.full] |= 1u << (pl.dev & 31);
         }
     }
-    char sched[200] = "";
-    if (g.nseg) {
-        int at = snprintf(sched, sizeof sched, " tapered 8 x [");
-        for (int b = 0; b < g.nb && at < (int)sizeof sched - 12; ++b)
-            at += snprintf(sched + at, sizeof sched - at, "%s%d", b ? " " : "", g.joff[b + 1] - g.joff[b]);
-        snprintf(sched + at, sizeof sched - at, "]");
-    }
     if (env.verbose)
-        fprintf(stderr, "[amt march] nk %d idim %d window i %d..%d, %d rows -> %s %s: %d waves, %zu B LDS, %d tiles x %d blocks of %d rows%s\n",
-                p.nk, p.idim, p.i0, p.i1, nj, pl.entry->name, pl.full ? "FULL" : "ragged", pl.nw, pl.lds, g.ntile_i,
-                g.nseg ? 8 * g.nb : g.njblk, g.jrows, sched);
-    snprintf(pl.label, sizeof pl.label, "%s %s jrows=%d%s", pl.entry->name, pl.full ? "FULL" : "ragged", g.jrows, sched);
+        fprintf(stderr, "[amt march] nk %d idim %d window i %d..%d, %d rows -> %s %s: %d waves, %zu B LDS, %d tiles x %d blocks of %d rows\n",
+                p.nk, p.idim, p.i0, p.i1, nj, pl.entry->name, pl.full ? "FULL" : "ragged", pl.nw, pl.lds, g.ntile_i, g.njblk, g.jrows);
+    snprintf(pl.label, sizeof pl.label, "%s %s jrows=%d", pl.entry->name, pl.full ? "FULL" : "ragged", g.jrows);
     snprintf(g_march_last, sizeof g_march_last, "%s", pl.label);
     pl.ok = true;
     return true;
@@ -1383,6 +1267,7 @@ extern "C" int amt_march_selectable(char *buf, int cap)
                 AmtParams<double> pd = {};
                 AmtParams<float> pf = {};
                 pd.nk = pf.nk = nk;
+                pd.kdim = pf.kdim = nk + 1;                          // kme = kte: one level row behind the window's last
                 pd.idim = pf.idim = lay ? 4099 : 4160;
                 pd.i0 = pf.i0 = 32;
                 pd.i1 = pf.i1 = win ? 95 : 4095;
