@@ -141,9 +141,10 @@ int amt_host_release(void);
  * call uploads.  With the cache enabled the calling thread keeps whole-window device copies of these five
  * between calls -- keyed on their host addresses and every extent -- and uploads one again only after
  * amt_host_invalidate(ptr) (NULL: all of them; call it when a new RK stage has rewritten them, and when an
- * array was freed and another one allocated at the same address: the key is the address, not the contents).  u, v, t, mu
- * and level 1 of ww, which change from sub-step to sub-step, the 2-D and 1-D arrays (1/NK of the data) and all
- * outputs cross the link on every call as before.  The reference re-uploads everything on every call
+ * array was freed and another one allocated at the same address: the key is the address, not the contents).  Since r04
+ * the 2-D and 1-D inputs that are constant over the sub-steps as well (mut, muu, muv, mu_tend, the four map factors, dnw,
+ * fnm, fnp, rdnw) are kept the same way.  u, v, t, mu and level 1 of ww, which change from sub-step to sub-step, and all
+ * outputs cross the link on every call as before (unless deferred, below).  The reference re-uploads everything on every call
  * (advance_mu_t_no_async.cu:245-306).
  * amt_host_cache_check(1) is the debug mode: every call checksums the cached arrays on the host and fails with
  * AMT_ERR_PRECONDITION if one changed without an invalidate (it reads the whole arrays: slow).
@@ -151,6 +152,26 @@ int amt_host_release(void);
 int amt_host_cache_enable(int on);
 int amt_host_cache_check(int on);
 int amt_host_invalidate(const void *host_ptr);
+
+/* Deferred outputs of the one-shot calls (per calling host thread; off by default): the practical form of a resident
+ * small-step loop at the reference's own boundary (every call of advance_mu_t_no_async.cu brings all outputs down,
+ * :366-390, and takes them up again with the next call, :245-306).  amt_host_defer(ptr, 1) marks one of the routine's
+ * outputs -- ww, t, t_ave, mu, muave, muts, mudf, recognised by its host address in the calls that follow; NULL: all
+ * seven -- as DEFERRED: it stays on the device after a call (a whole-window copy, like the cached inputs) and nothing of it
+ * is written to the host array; the in/out ones (level 1 of ww, t, mu) are then also not uploaded by the next call --
+ * the device copy is the truth.  amt_host_fetch(ptr) (NULL: every stale one) brings the window's cells down when the
+ * caller -- the next routine of the acoustic loop, or the end of the loop -- really needs host values; amt_host_stale(ptr)
+ * (NULL: any) says whether the device copy is newer than the host array.  amt_host_invalidate(ptr) says the HOST array
+ * was rewritten and is the truth again (the next call uploads it).  With the residency cache on as well, a sub-step
+ * uploads u, v and the 2-D / 1-D inputs only.  amt_host_defer(ptr, 0) fetches what is stale and makes the array an
+ * ordinary output again; so do amt_host_release() and a call with other extents or other arrays (nothing the device
+ * alone holds is ever dropped by the library; a thread that ENDS without amt_host_release() loses it).
+ * In the debug mode (amt_host_cache_check(1)) the window's cells of a deferred host array are overwritten with NaN
+ * canaries after every call, so that a consumer reading the stale array computes NaNs instead of silently using old
+ * values, and a call that finds them changed without an invalidate fails with AMT_ERR_PRECONDITION. */
+int amt_host_defer(const void *host_ptr, int on);
+int amt_host_fetch(const void *host_ptr);
+int amt_host_stale(const void *host_ptr);
 
 /* ------------------------------------------------------------------------
  * (2) Device-resident drop-ins: the same call with every array pointer in

@@ -42,6 +42,12 @@ def main():
     ap.add_argument("--gnj", type=int, default=0, help="rows of the whole domain (0: the slab is the domain)")
     ap.add_argument("--seed", type=int, default=12345)
     a = ap.parse_args()
+    # Idle OpenMP threads spin instead of sleeping (both runtimes; set before either is loaded): the harness runs one short
+    # parallel region per sweep, and on the GPU boxes of this pool (16 granted CPUs of 256) waking sleeping workers costs up
+    # to half the sweep -- 16 threads, 2 x EPYC 9575F, Fortran path 2.5-2.6 Gcells/s by default, 2.9-3.0 active, 1.9-2.0
+    # passive; the C port 1.5-2.9 in any mode (profiles/r04_raw/cpu_threads.txt).  A caller's own setting wins.
+    import os
+    os.environ.setdefault("OMP_WAIT_POLICY", "active")
     import importlib.util
     spec = importlib.util.spec_from_file_location("amt_oracle", HERE / "oracle.py")
     O = importlib.util.module_from_spec(spec)

@@ -23,7 +23,7 @@
 !     jts:jte, the scheme sketched in the reference driver (advance_mu_t_driver.f90:175-209).
 !
 ! Build knobs (-cpp): AMT_IB columns per i block (default 1024: the fastest of 64 ... 4096 on 16 cores of 2 x EPYC 9575F,
-! profiles/r04_cpu_fortran_tune.txt), AMT_J_OUTER=1 the r03 loop order (A/B only).
+! profiles/r04_raw/cpu_fortran_tune.txt), AMT_J_OUTER=1 the r03 loop order (A/B only).
 !
 ! Every expression keeps the reference's association and the file is compiled with
 ! -ffp-contract=off, so the results are the reference's bits: tests/test_fortran_cpu.py holds it

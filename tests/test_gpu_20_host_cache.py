@@ -72,6 +72,32 @@ def test_a_changed_constant_without_invalidate_is_detected_and_with_it_is_used(c
     assert_patch_equal(pkg, got, want, "after invalidate")
 
 
+def test_the_2d_and_1d_constants_are_cached_too(cache, oracle):
+    """r04: mut, muu, muv, mu_tend, the map factors and the 1-D metrics stay on the device as well: a changed msfty or dnw
+    without an invalidate is refused by the checksum mode (and named), and used after one."""
+    pkg = cache
+    b = pkg.synth.domain_bounds(72, 9, 14)
+    got = pkg.synth.make_patch(b, pkg.GridConfig(specified=True), dtype=np.float32, seed=13)
+    want = got.copy()
+    pkg.advance_mu_t(*got.args())
+    oracle.advance_mu_t(*want.args())
+    assert_patch_equal(pkg, got, want, "first call")
+    for p in (got, want):
+        p.arrays["msfty"] *= 1.01
+        p.arrays["dnw"] *= 0.99
+    with pytest.raises(pkg.AmtError) as err:
+        pkg.advance_mu_t(*got.args())
+    assert err.value.status == 2 and ("msfty" in str(err.value) or "dnw" in str(err.value))
+    pkg.host_invalidate(got.arrays["msfty"])
+    with pytest.raises(pkg.AmtError) as err:
+        pkg.advance_mu_t(*got.args())
+    assert "dnw" in str(err.value)
+    pkg.host_invalidate(got.arrays["dnw"])
+    pkg.advance_mu_t(*got.args())
+    oracle.advance_mu_t(*want.args())
+    assert_patch_equal(pkg, got, want, "after the invalidates")
+
+
 def test_without_the_check_mode_a_stale_constant_is_really_not_uploaded(pkg, oracle):
     """The cache does what it says: with the check off, a changed-but-not-invalidated ft is NOT seen by the
     device (the result is the oracle's on the OLD ft), and is seen after amt_host_invalidate."""
@@ -115,4 +141,155 @@ def test_cache_off_is_the_default_and_the_key_follows_the_arrays(pkg, oracle):
             assert_patch_equal(pkg, got, want, f"key change seed {seed}")
     finally:
         pkg.host_cache_enable(False)
+        pkg.load_library().amt_host_release()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# deferred outputs (amt_host_defer / amt_host_fetch / amt_host_stale): ww, t, t_ave, mu, muave, muts, mudf stay on the
+# device from sub-step to sub-step and come down once
+# ---------------------------------------------------------------------------------------------------------------
+DEFERRABLE = ("ww", "t", "t_ave", "mu", "muave", "muts", "mudf")
+
+
+@pytest.fixture()
+def deferred(pkg):
+    pkg.host_cache_enable(True, check=False)
+    pkg.host_defer(None, True)
+    yield pkg
+    pkg.host_defer(None, False)
+    pkg.host_cache_enable(False, check=False)
+    pkg.load_library().amt_host_release()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("rows", [None, 7])
+def test_sub_step_loop_with_deferred_outputs_matches_the_oracle(deferred, oracle, monkeypatch, dtype, rows):
+    """Five sub-steps with u, v changing in between; the host copies of the seven outputs are NOT touched until the
+    fetch at the end of the loop, and then hold the oracle's bits (one chunk and many)."""
+    pkg = deferred
+    if rows:
+        monkeypatch.setenv("AMT_STREAM_ROWS", str(rows))
+    b = pkg.synth.domain_bounds(150, 24, 40)
+    got = pkg.synth.make_patch(b, pkg.GridConfig(specified=True), dtype=dtype, seed=21)
+    want = got.copy()
+    before = {n: got.arrays[n].copy() for n in DEFERRABLE}
+    rng = np.random.default_rng(9)
+    for step in range(5):
+        if step:
+            state = rng.bit_generator.state
+            _perturb(got, rng, ("u", "v"))
+            rng.bit_generator.state = state
+            _perturb(want, rng, ("u", "v"))
+        pkg.advance_mu_t(*got.args())
+        oracle.advance_mu_t(*want.args())
+        for n in DEFERRABLE:                                       # nothing came down
+            assert np.array_equal(got.arrays[n].view(np.uint8), before[n].view(np.uint8)), (step, n)
+            assert pkg.host_stale(got.arrays[n])
+    pkg.host_fetch(None)
+    assert not pkg.host_stale(None)
+    assert_patch_equal(pkg, got, want, f"deferred loop ({np.dtype(dtype).name}, rows={rows})")
+
+
+def test_deferring_some_outputs_only_and_fetching_one_by_one(pkg, oracle):
+    """Only t and mu deferred: ww, t_ave, muave ... come down with every call as before; a fetch of t leaves mu stale."""
+    pkg.host_defer(None, False)
+    b = pkg.synth.domain_bounds(96, 12, 20)
+    got = pkg.synth.make_patch(b, pkg.GridConfig(nested=True), dtype=np.float64, seed=4)
+    want = got.copy()
+    try:
+        pkg.host_defer(got.arrays["t"], True)
+        pkg.host_defer(got.arrays["mu"], True)
+        t0 = got.arrays["t"].copy()
+        for _ in range(3):
+            pkg.advance_mu_t(*got.args())
+            oracle.advance_mu_t(*want.args())
+            for n in ("ww", "t_ave", "muave", "muts", "mudf"):
+                assert np.array_equal(got.arrays[n].view(np.uint8), want.arrays[n].view(np.uint8)), n
+            assert np.array_equal(got.arrays["t"], t0)
+        assert pkg.host_stale(got.arrays["t"]) and pkg.host_stale(got.arrays["mu"]) and not pkg.host_stale(got.arrays["ww"])
+        pkg.host_fetch(got.arrays["t"])
+        assert not pkg.host_stale(got.arrays["t"]) and pkg.host_stale(got.arrays["mu"])
+        assert np.array_equal(got.arrays["t"].view(np.uint8), want.arrays["t"].view(np.uint8))
+        pkg.host_defer(got.arrays["mu"], False)                    # turning it off brings it down
+        assert not pkg.host_stale(None)
+        assert_patch_equal(pkg, got, want, "partial deferral")
+        pkg.host_defer(got.arrays["t"], False)
+        pkg.advance_mu_t(*got.args())                              # an ordinary call again: uploads t from the host
+        oracle.advance_mu_t(*want.args())
+        assert_patch_equal(pkg, got, want, "after deferral")
+    finally:
+        pkg.host_defer(None, False)
+        pkg.load_library().amt_host_release()
+
+
+def test_host_rewrite_of_a_deferred_array_needs_an_invalidate(deferred, oracle):
+    """The caller rewrites t on the host between two sub-steps (say, a physics tendency was added there): with
+    amt_host_invalidate the host array is the truth and goes up again; the other six stay on the device."""
+    pkg = deferred
+    b = pkg.synth.domain_bounds(80, 10, 16)
+    got = pkg.synth.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=6)
+    want = got.copy()
+    pkg.advance_mu_t(*got.args())
+    oracle.advance_mu_t(*want.args())
+    pkg.host_fetch(got.arrays["t"])                                # the caller needs t on the host ...
+    for p in (got, want):
+        p.arrays["t"] += 0.5                                       # ... changes it ...
+    pkg.host_invalidate(got.arrays["t"])                           # ... and says so
+    pkg.advance_mu_t(*got.args())
+    oracle.advance_mu_t(*want.args())
+    pkg.host_fetch(None)
+    assert_patch_equal(pkg, got, want, "host rewrite + invalidate")
+
+
+def test_debug_mode_makes_a_stale_host_read_loud_and_catches_a_silent_host_write(pkg, oracle):
+    """amt_host_cache_check(1) with deferred outputs: after a call the window's cells of a deferred HOST array hold NaN
+    canaries (a consumer that forgot the fetch computes NaNs, it does not silently use the old values); cells outside the
+    window keep their values; a host write into a stale array without amt_host_invalidate is refused by the next call."""
+    pkg.host_cache_enable(True, check=True)
+    pkg.host_defer(None, True)
+    try:
+        b = pkg.synth.domain_bounds(64, 9, 14)
+        got = pkg.synth.make_patch(b, pkg.GridConfig(specified=True), dtype=np.float32, seed=2)
+        want = got.copy()
+        orig_t = got.arrays["t"].copy()
+        pkg.advance_mu_t(*got.args())
+        oracle.advance_mu_t(*want.args())
+        win = pkg.compute_window(got.config, b.ids, b.ide, b.jds, b.jde, b.its, b.ite, b.jts, b.jte, b.kts, b.kte)
+        i0, i1, j0, j1 = win[0], win[1], win[2], win[3]
+        inside = np.zeros(orig_t.shape, dtype=bool)
+        inside[j0 - b.jms:j1 - b.jms + 1, 1 - b.kms:b.kte - b.kms, i0 - b.ims:i1 - b.ims + 1] = True
+        t = got.arrays["t"]
+        assert np.isnan(t[inside]).all() and pkg.host_stale(t)       # a stale read is loud
+        assert np.array_equal(t[~inside], orig_t[~inside])           # nothing outside the window was touched
+        assert np.isnan(got.arrays["mu"][j0 - b.jms:j1 - b.jms + 1, i0 - b.ims:i1 - b.ims + 1]).all()
+        t[inside] = 1.0                                              # a host write without an invalidate
+        with pytest.raises(pkg.AmtError) as err:
+            pkg.advance_mu_t(*got.args())
+        assert err.value.status == 2 and "deferred output t" in str(err.value)
+        pkg.host_fetch(None)                                         # the device still holds the truth
+        assert_patch_equal(pkg, got, want, "fetch after the refused call")
+    finally:
+        pkg.host_defer(None, False)
+        pkg.host_cache_enable(False, check=False)
+        pkg.load_library().amt_host_release()
+
+
+def test_another_patch_or_a_release_never_drops_what_only_the_device_holds(pkg, oracle):
+    pkg.host_defer(None, True)
+    try:
+        b = pkg.synth.domain_bounds(48, 7, 10)
+        a1 = pkg.synth.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=1)
+        w1 = a1.copy()
+        pkg.advance_mu_t(*a1.args())
+        oracle.advance_mu_t(*w1.args())
+        b2 = pkg.synth.domain_bounds(40, 5, 9)
+        a2 = pkg.synth.make_patch(b2, pkg.GridConfig(), dtype=np.float64, seed=2)      # other arrays, other extents
+        w2 = a2.copy()
+        pkg.advance_mu_t(*a2.args())                                 # flushes patch 1's outputs to ITS host arrays first
+        oracle.advance_mu_t(*w2.args())
+        assert_patch_equal(pkg, a1, w1, "flushed by the key change")
+        pkg.load_library().amt_host_release()                        # flushes patch 2
+        assert_patch_equal(pkg, a2, w2, "flushed by amt_host_release")
+    finally:
+        pkg.host_defer(None, False)
         pkg.load_library().amt_host_release()

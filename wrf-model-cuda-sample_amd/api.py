@@ -148,6 +148,28 @@ def host_cache_enable(on: bool = True, check: bool = False) -> None:
     _lib.check(L.amt_host_cache_check(int(bool(check))))
 
 
+def host_defer(array=None, on: bool = True) -> None:
+    """Deferred outputs of the one-shot (numpy) calls of the calling thread (header section 1: amt_host_defer): the
+    output ``array`` (None: all seven) stays on the device after a call until ``host_fetch``."""
+    L = _lib.load_library()
+    ptr = None if array is None else array.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(L.amt_host_defer(ptr, int(bool(on))))
+
+
+def host_fetch(array=None) -> None:
+    """Bring the window's cells of a deferred output (None: every stale one) down to its host array."""
+    L = _lib.load_library()
+    ptr = None if array is None else array.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(L.amt_host_fetch(ptr))
+
+
+def host_stale(array=None) -> bool:
+    """Is the device copy of a deferred output (None: of any) newer than the host array?"""
+    L = _lib.load_library()
+    ptr = None if array is None else array.ctypes.data_as(ctypes.c_void_p)
+    return bool(L.amt_host_stale(ptr))
+
+
 def host_invalidate(array=None) -> None:
     """The host array (numpy) changed since the last call: upload it again.  None: all cached arrays."""
     L = _lib.load_library()

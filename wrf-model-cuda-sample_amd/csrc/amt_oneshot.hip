@@ -29,25 +29,53 @@ struct HostWorkspace {
     size_t stage_size = 0;
     static constexpr size_t keep_limit = (size_t)1 << 30;   // larger arenas are not kept between calls
 
-    // Residency cache (amt_host_cache_enable): whole-window device copies of the five 3-D inputs that are
-    // constant over the acoustic sub-steps of a Runge-Kutta stage -- ww_1, u_1, v_1, t_1, ft -- kept between
-    // calls and uploaded again only after amt_host_invalidate.  Keyed on the host pointers and every extent.
-    static constexpr int NRES = 5;
-    struct Resident {
-        bool enabled = false, check = false;
-        char *buf[NRES] = {};
-        size_t bytes_each = 0;
-        bool valid[NRES] = {};
-        uint64_t sum[NRES] = {};                              // checksum of what was uploaded (check mode)
-        const void *host[NRES] = {};
-        int key[16] = {};                                     // element size, extents, window rows
+    // Arrays that stay on the device between calls of this thread, as whole-window copies keyed on the host
+    // pointers and every extent:
+    //  * residency cache (amt_host_cache_enable): the inputs that are constant over the acoustic sub-steps of a
+    //    Runge-Kutta stage -- the five 3-D ones ww_1, u_1, v_1, t_1, ft, and (r04) the eight 2-D and four 1-D ones
+    //    mut, muu, muv, mu_tend, msfuy, msfvx_inv, msftx, msfty, dnw, fnm, fnp, rdnw -- go up again only after
+    //    amt_host_invalidate;
+    //  * deferred outputs (amt_host_defer): ww, t, t_ave, mu, muave, muts, mudf stay on the device after the call;
+    //    the device copy is the truth until amt_host_fetch brings the window's cells down (or amt_host_invalidate
+    //    says the host array was rewritten and is the truth again); the in/out ones (level 1 of ww, t, mu) go up
+    //    only while the device copy is not valid.
+    static constexpr int NKEEP = 24;
+    static constexpr int NCACHE = 17;                         // the first NCACHE entries are the cached inputs
+    struct Kept {
+        bool enabled = false, check = false;                  // cache on; checksum / canary debug mode
+        bool defer_all = false;
+        const void *defer_ptr[16] = {};
+        int ndefer = 0;
+        char *buf[NKEEP] = {};
+        size_t bytes[NKEEP] = {};
+        bool active[NKEEP] = {};                              // kept by the calls of the current key
+        bool valid[NKEEP] = {};                               // the device copy is current
+        bool stale[NKEEP] = {};                               // deferred: the device copy is NEWER than the host array
+        uint64_t sum[NKEEP] = {};                             // check mode: checksum of what was uploaded / of the canary
+        const void *host[NKEEP] = {};
+        int key[16] = {};                                     // element size, extents, window, device
+        // geometry of the window the copies cover (amt_host_fetch works from it)
+        size_t esize = 0;
+        long idim = 0, kdim = 0, i0 = 0, ni = 0, k1 = 0, nk = 0, j_start = 0, j_end = 0, jms = 0;
+        bool deferred(const void *ptr) const
+        {
+            if (defer_all) return true;
+            for (int q = 0; q < ndefer; ++q)
+                if (defer_ptr[q] == ptr) return true;
+            return false;
+        }
+        bool any_stale() const
+        {
+            for (int r = 0; r < NKEEP; ++r)
+                if (stale[r]) return true;
+            return false;
+        }
         void drop()
         {
-            for (int r = 0; r < NRES; ++r) {
+            for (int r = 0; r < NKEEP; ++r) {
                 if (buf[r]) (void)hipFree(buf[r]);
-                buf[r] = nullptr; valid[r] = false; host[r] = nullptr; sum[r] = 0;
+                buf[r] = nullptr; bytes[r] = 0; active[r] = valid[r] = stale[r] = false; host[r] = nullptr; sum[r] = 0;
             }
-            bytes_each = 0;
         }
     } res;
 
@@ -63,11 +91,12 @@ struct HostWorkspace {
                 if (e) (void)hipEventDestroy(e);
         if (arena) (void)hipFree(arena);
         if (stage) (void)hipHostFree(stage);
-        const bool en = res.enabled, ck = res.check;
+        Kept keep = res;                                     // the thread's settings outlive its buffers
         res.drop();
         if (sw) (void)hipSetDevice(prev);
         *this = HostWorkspace();
-        res.enabled = en; res.check = ck;                    // settings of the thread outlive its buffers
+        res.enabled = keep.enabled; res.check = keep.check; res.defer_all = keep.defer_all; res.ndefer = keep.ndefer;
+        memcpy(res.defer_ptr, keep.defer_ptr, sizeof res.defer_ptr);
     }
     // A worker thread's workspace is freed when the thread ends.  The main thread's destructor
     // runs at process exit only, possibly from a signal path with a HIP call on the stack: leave
@@ -137,10 +166,106 @@ struct WorkspaceScope {
 };
 }  // namespace
 
+
+// item index (argument position among the 26 arrays) and rank of every kept field: first the cached inputs, then the
+// deferrable outputs
+static const int kKeepField[HostWorkspace::NKEEP] = {1, 3, 5, 14, 16, 7, 10, 11, 17, 22, 23, 24, 25, 18, 19, 20, 21,
+                                                     /* deferred: */ 0, 13, 15, 6, 8, 9, 12};
+static const int kKeepRank[HostWorkspace::NKEEP] = {3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 3, 3, 3, 2, 2, 2, 2};
+static const char *const kKeepName[HostWorkspace::NKEEP] = {"ww_1", "u_1", "v_1", "t_1", "ft", "mut", "muu", "muv", "mu_tend", "msfuy",
+                                                            "msfvx_inv", "msftx", "msfty", "dnw", "fnm", "fnp", "rdnw",
+                                                            "ww", "t", "t_ave", "mu", "muave", "muts", "mudf"};
+
+// 64-bit checksum of a byte range (check mode only: it reads the whole range; byte-wise loads of the head and tail,
+// memcpy-based word loads in between: the range need not be 8-byte aligned)
+static uint64_t amt_host_sum(const void *p, size_t bytes)
+{
+    const unsigned char *q = static_cast<const unsigned char *>(p);
+    uint64_t a = 0x9e3779b97f4a7c15ull, b = 0;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        memcpy(&w, q + i, 8);
+        a = (a ^ w) * 0x100000001b3ull;
+        b += w + (a >> 29);
+    }
+    for (; i < bytes; ++i) a = (a ^ q[i]) * 0x100000001b3ull;
+    return a ^ (b << 1);
+}
+
+namespace {
+// The window's cells of kept field r as a list of (host address, device address, bytes) runs is never built: the
+// strided copies below walk it.  dir > 0: device -> host (fetch); the canary and the checksum walk the host side.
+const uint64_t kCanary64 = 0x7ff8dead0badc0deull;             // a quiet NaN in fp64
+const uint32_t kCanary32 = 0x7fc0dead;                        // a quiet NaN in fp32
+
+// bring the window's cells of kept field r down to its host array (the strided copies of a normal call's download)
+hipError_t amt_keep_fetch(HostWorkspace &ws, int r)
+{
+    HostWorkspace::Kept &k = ws.res;
+    if (!k.buf[r] || !k.stale[r]) return hipSuccess;
+    char *host = static_cast<char *>(const_cast<void *>(k.host[r]));
+    const size_t es = k.esize, idim = (size_t)k.idim, kdim = (size_t)k.kdim;
+    const size_t nj = (size_t)(k.j_end - k.j_start + 1);
+    hipError_t e;
+    if (kKeepRank[r] == 3) {
+        if (k.nk <= 0) { k.stale[r] = false; return hipSuccess; }
+        hipMemcpy3DParms cp;
+        memset(&cp, 0, sizeof cp);
+        cp.srcPtr = make_hipPitchedPtr(k.buf[r], idim * es, idim, kdim);
+        cp.dstPtr = make_hipPitchedPtr(host, idim * es, idim, kdim);
+        cp.srcPos = make_hipPos((size_t)k.i0 * es, (size_t)k.k1, 1);
+        cp.dstPos = make_hipPos((size_t)k.i0 * es, (size_t)k.k1, (size_t)(k.j_start - k.jms));
+        cp.extent = make_hipExtent((size_t)k.ni * es, (size_t)k.nk, nj);
+        cp.kind = hipMemcpyDeviceToHost;
+        e = hipMemcpy3DAsync(&cp, ws.down);
+    } else {
+        e = hipMemcpy2DAsync(host + ((size_t)(k.j_start - k.jms) * idim + (size_t)k.i0) * es, idim * es,
+                             k.buf[r] + (idim + (size_t)k.i0) * es, idim * es, (size_t)k.ni * es, nj, hipMemcpyDeviceToHost, ws.down);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ws.down);
+    if (e == hipSuccess) k.stale[r] = false;
+    return e;
+}
+
+// check mode: the window's cells of a deferred host array are overwritten with NaN canaries after the call (a consumer
+// that reads the stale host array computes NaNs instead of silently using old values) -- or, with fill = false, checked
+// to still hold them (a host write without amt_host_invalidate would otherwise be lost)
+bool amt_keep_canary(HostWorkspace::Kept &k, int r, bool fill)
+{
+    char *host = static_cast<char *>(const_cast<void *>(k.host[r]));
+    const size_t es = k.esize, idim = (size_t)k.idim, kdim = (size_t)k.kdim;
+    const size_t levels = kKeepRank[r] == 3 ? (size_t)k.nk : 1, kd = kKeepRank[r] == 3 ? kdim : 1, k1 = kKeepRank[r] == 3 ? (size_t)k.k1 : 0;
+    for (long j = k.j_start; j <= k.j_end; ++j)
+        for (size_t l = 0; l < levels; ++l) {
+            char *row = host + ((((size_t)(j - k.jms)) * kd + k1 + l) * idim + (size_t)k.i0) * es;
+            for (long i = 0; i < k.ni; ++i) {
+                if (fill) {
+                    if (es == 8) memcpy(row + (size_t)i * 8, &kCanary64, 8);
+                    else memcpy(row + (size_t)i * 4, &kCanary32, 4);
+                } else if (memcmp(row + (size_t)i * es, es == 8 ? (const void *)&kCanary64 : (const void *)&kCanary32, es) != 0) {
+                    return false;
+                }
+            }
+        }
+    return true;
+}
+
+// everything the device holds that the host does not: brought down before the copies are given up
+int amt_keep_flush(HostWorkspace &ws)
+{
+    if (ws.device < 0 || !ws.res.any_stale()) return AMT_OK;
+    DeviceScope dev(ws.device);
+    for (int r = 0; r < HostWorkspace::NKEEP; ++r) AMT_HIP(amt_keep_fetch(ws, r));
+    return AMT_OK;
+}
+}  // namespace
+
 extern "C" int amt_host_release(void)
 {
+    const int rc = amt_keep_flush(tl_workspace);              // what only the device holds comes down before the buffers go
     tl_workspace.release();
-    return AMT_OK;
+    return rc;
 }
 
 extern "C" int amt_host_cache_enable(int on)
@@ -150,7 +275,10 @@ extern "C" int amt_host_cache_enable(int on)
         DeviceScope dev(ws.device);
         for (hipStream_t st : {ws.up, ws.comp, ws.down})
             if (st) (void)hipStreamSynchronize(st);
-        ws.res.drop();
+        for (int r = 0; r < HostWorkspace::NCACHE; ++r) {        // the cached inputs go; deferred outputs are another setting
+            if (ws.res.buf[r]) (void)hipFree(ws.res.buf[r]);
+            ws.res.buf[r] = nullptr; ws.res.bytes[r] = 0; ws.res.active[r] = ws.res.valid[r] = false; ws.res.host[r] = nullptr;
+        }
     }
     ws.res.enabled = on != 0;
     return AMT_OK;
@@ -164,24 +292,57 @@ extern "C" int amt_host_cache_check(int on)
 
 extern "C" int amt_host_invalidate(const void *host_ptr)
 {
-    HostWorkspace::Resident &r = tl_workspace.res;
-    int hit = 0;
-    for (int q = 0; q < HostWorkspace::NRES; ++q)
-        if (!host_ptr || r.host[q] == host_ptr) { r.valid[q] = false; ++hit; }
-    (void)hit;                                                // an array that is not cached is uploaded anyway
+    // "the host array was rewritten": a cached input goes up again with the next call; for a deferred output the HOST
+    // is the truth again (whatever the device still held for it is given up)
+    HostWorkspace::Kept &r = tl_workspace.res;
+    for (int q = 0; q < HostWorkspace::NKEEP; ++q)
+        if (!host_ptr || r.host[q] == host_ptr) { r.valid[q] = false; r.stale[q] = false; }
+    return AMT_OK;                                            // an array that is not kept is uploaded anyway
+}
+
+extern "C" int amt_host_defer(const void *host_ptr, int on)
+{
+    HostWorkspace &ws = tl_workspace;
+    HostWorkspace::Kept &k = ws.res;
+    if (on) {
+        if (!host_ptr) { k.defer_all = true; return AMT_OK; }
+        if (k.deferred(host_ptr)) return AMT_OK;
+        if (k.ndefer >= 16) return amt_fail(AMT_ERR_INVALID_ARG, "amt_host_defer: more than 16 deferred arrays");
+        k.defer_ptr[k.ndefer++] = host_ptr;
+        return AMT_OK;
+    }
+    // off: what the device holds for it comes down first, then the array is an ordinary output again
+    for (int r = HostWorkspace::NCACHE; r < HostWorkspace::NKEEP; ++r)
+        if (k.buf[r] && (!host_ptr || k.host[r] == host_ptr)) {
+            if (k.stale[r] && ws.device >= 0) {
+                DeviceScope dev(ws.device);
+                AMT_HIP(amt_keep_fetch(ws, r));
+            }
+            k.valid[r] = false;                               // the next call uploads from the host again
+        }
+    if (!host_ptr) { k.defer_all = false; k.ndefer = 0; return AMT_OK; }
+    if (k.defer_all) return amt_fail(AMT_ERR_INVALID_ARG, "amt_host_defer(ptr, 0) after amt_host_defer(NULL, 1): turn all off with NULL");
+    for (int q = 0; q < k.ndefer; ++q)
+        if (k.defer_ptr[q] == host_ptr) { k.defer_ptr[q] = k.defer_ptr[--k.ndefer]; break; }
     return AMT_OK;
 }
 
-// 64-bit checksum of a host array's rows (check mode only: it reads the whole array)
-static uint64_t amt_host_sum(const void *p, size_t bytes)
+extern "C" int amt_host_fetch(const void *host_ptr)
 {
-    const uint64_t *w = static_cast<const uint64_t *>(p);
-    const size_t n = bytes / 8;
-    uint64_t a = 0x9e3779b97f4a7c15ull, b = 0;
-    for (size_t i = 0; i < n; ++i) { a = (a ^ w[i]) * 0x100000001b3ull; b += w[i] + (a >> 29); }
-    const unsigned char *tail = static_cast<const unsigned char *>(p) + n * 8;
-    for (size_t i = 0; i < bytes % 8; ++i) a = (a ^ tail[i]) * 0x100000001b3ull;
-    return a ^ (b << 1);
+    HostWorkspace &ws = tl_workspace;
+    if (ws.device < 0) return AMT_OK;
+    DeviceScope dev(ws.device);
+    for (int r = HostWorkspace::NCACHE; r < HostWorkspace::NKEEP; ++r)
+        if (!host_ptr || ws.res.host[r] == host_ptr) AMT_HIP(amt_keep_fetch(ws, r));
+    return AMT_OK;
+}
+
+extern "C" int amt_host_stale(const void *host_ptr)
+{
+    const HostWorkspace::Kept &k = tl_workspace.res;
+    for (int r = HostWorkspace::NCACHE; r < HostWorkspace::NKEEP; ++r)
+        if (k.stale[r] && (!host_ptr || k.host[r] == host_ptr)) return 1;
+    return 0;
 }
 
 // One-shot call = upload, kernel, download.  Three regimes, chosen per call:
@@ -317,46 +478,73 @@ static int amt_host_call(const AmtArgs<T> &h)
     }
     const size_t arena_end = ws.used;
 
-    // ---- residency cache: whole-window copies of ww_1, u_1, v_1, t_1, ft ----------------------------------
-    static const int res_field[HostWorkspace::NRES] = {1, 3, 5, 14, 16};
+    // ---- arrays kept on the device between calls: cached inputs and deferred outputs (whole-window copies) -----
     int res_of[26];
     for (int f = 0; f < 26; ++f) res_of[f] = -1;
-    HostWorkspace::Resident &res = ws.res;
-    bool res_upload[HostWorkspace::NRES] = {};
-    if (res.enabled) {
-        const int key[16] = {(int)sizeof(T), h.ims, h.ime, h.kms, h.kme, h.jms, h.jme, w.j_start, w.j_end, p.i0, p.i1, p.nk, device, 0, 0, 0};
-        const size_t each = r3 * wrow * sizeof(T);
-        bool same = res.bytes_each == each && memcmp(res.key, key, sizeof key) == 0;
-        for (int r = 0; r < HostWorkspace::NRES && same; ++r) same = res.host[r] == items[res_field[r]].host;
+    HostWorkspace::Kept &res = ws.res;
+    bool res_upload[HostWorkspace::NKEEP] = {};
+    long res_hi[HostWorkspace::NKEEP];                         // highest row uploaded so far in this call
+    for (int r = 0; r < HostWorkspace::NKEEP; ++r) res_hi[r] = (long)w.j_start - 2;
+    {
+        bool want[HostWorkspace::NKEEP];
+        bool any_want = false;
+        for (int r = 0; r < HostWorkspace::NKEEP; ++r) {
+            want[r] = r < HostWorkspace::NCACHE ? res.enabled : res.deferred(items[kKeepField[r]].host);
+            any_want = any_want || want[r];
+        }
+        const int key[16] = {(int)sizeof(T), h.ims, h.ime, h.kms, h.kme, h.jms, h.jme, w.j_start, w.j_end, p.i0, p.i1, p.nk, p.k1, device, 0, 0};
+        bool same = memcmp(res.key, key, sizeof key) == 0;
+        for (int r = 0; r < HostWorkspace::NKEEP && same; ++r)
+            same = want[r] == res.active[r] && (!want[r] || res.host[r] == items[kKeepField[r]].host);
         if (!same) {
-            // another patch, another layout or other arrays: start over (nothing is in flight between calls)
+            // another patch, another layout, other arrays or other settings: what only the device holds goes down to the
+            // arrays it belongs to, then start over (nothing is in flight between calls)
+            rc = amt_keep_flush(ws);
+            if (rc != AMT_OK) return rc;
             res.drop();
-            for (int r = 0; r < HostWorkspace::NRES; ++r) {
+            memcpy(res.key, key, sizeof key);
+            res.esize = sizeof(T); res.idim = idim; res.kdim = kdim; res.i0 = p.i0; res.ni = (long)ni; res.k1 = p.k1; res.nk = p.nk;
+            res.j_start = w.j_start; res.j_end = w.j_end; res.jms = h.jms;
+            for (int r = 0; r < HostWorkspace::NKEEP; ++r) {
+                if (!want[r]) continue;
+                const size_t each = (kKeepRank[r] == 3 ? r3 * wrow : kKeepRank[r] == 2 ? r2 * wrow : n1) * sizeof(T);
                 const hipError_t e = hipMalloc((void **)&res.buf[r], each);
                 if (e != hipSuccess) {
                     (void)hipGetLastError();
                     res.drop();
-                    return amt_fail(AMT_ERR_ALLOC, "residency cache: hipMalloc of %zu bytes failed (amt_host_cache_enable(0) runs without it)", each);
+                    memset(res.key, 0, sizeof res.key);
+                    return amt_fail(AMT_ERR_ALLOC, "kept arrays: hipMalloc of %zu bytes for %s failed (amt_host_cache_enable(0) / "
+                                    "amt_host_defer(NULL, 0) run without them)", each, kKeepName[r]);
                 }
-                res.host[r] = items[res_field[r]].host;
+                res.bytes[r] = each;
+                res.active[r] = true;
+                res.host[r] = items[kKeepField[r]].host;
             }
-            res.bytes_each = each;
-            memcpy(res.key, key, sizeof key);
         }
-        for (int r = 0; r < HostWorkspace::NRES; ++r) {
-            res_of[res_field[r]] = r;
-            res_upload[r] = !res.valid[r];
-            if (res.check) {
-                // debug mode: a cached array that changed on the host without amt_host_invalidate is an error
-                const T *rows0 = items[res_field[r]].host + (size_t)(w.j_start - 1 - h.jms) * r3;
-                const uint64_t now_sum = amt_host_sum(rows0, each);
+        for (int r = 0; r < HostWorkspace::NKEEP && any_want; ++r) {
+            if (!res.active[r]) continue;
+            const int f = kKeepField[r];
+            res_of[f] = r;
+            res_upload[r] = !res.valid[r] && items[f].in;
+            if (!res.check) continue;
+            if (r < HostWorkspace::NCACHE) {
+                // debug mode: a cached array that changed on the host without amt_host_invalidate is an error.  The
+                // checksum covers exactly the rows a call uploads (rows j_start-1 / j_end+1 only for the halo arrays)
+                const int lo = items[f].halo ? w.j_start - 1 : w.j_start, hi = items[f].halo ? w.j_end + 1 : w.j_end;
+                const uint64_t now_sum = kKeepRank[r] == 3 ? amt_host_sum(items[f].host + (size_t)(lo - h.jms) * r3, (size_t)(hi - lo + 1) * r3 * sizeof(T))
+                                       : kKeepRank[r] == 2 ? amt_host_sum(items[f].host + (size_t)(w.j_start - 1 - h.jms) * r2, r2 * wrow * sizeof(T))
+                                                           : amt_host_sum(items[f].host, n1 * sizeof(T));
                 if (res.valid[r] && now_sum != res.sum[r]) {
-                    static const char *names[HostWorkspace::NRES] = {"ww_1", "u_1", "v_1", "t_1", "ft"};
                     res.valid[r] = false;
                     return amt_fail(AMT_ERR_PRECONDITION, "residency cache: %s changed on the host since it was uploaded "
-                                    "but amt_host_invalidate was not called for it (amt_host_cache_check)", names[r]);
+                                    "but amt_host_invalidate was not called for it (amt_host_cache_check)", kKeepName[r]);
                 }
                 res.sum[r] = now_sum;
+            } else if (res.stale[r] && !amt_keep_canary(res, r, false)) {
+                // debug mode: the host array of a deferred output was written while the device held the truth
+                return amt_fail(AMT_ERR_PRECONDITION, "deferred output %s was written on the host while its device copy was newer: "
+                                "call amt_host_invalidate for it (the host is the truth) or amt_host_fetch before writing "
+                                "(amt_host_cache_check)", kKeepName[r]);
             }
         }
     }
@@ -381,6 +569,11 @@ static int amt_host_call(const AmtArgs<T> &h)
         if (it.rank == 3 || !it.in) continue;                 // muave, muts, mudf: outputs only
         const size_t n = it.rank == 1 ? n1 : r2 * wrow;
         const T *src = it.rank == 1 ? it.host : it.host + (size_t)(w.j_start - 1 - h.jms) * r2;
+        if (res_of[f] >= 0) {                                 // cached 2-D / 1-D input, deferred mu: up only while the device copy is not valid
+            if (res_upload[res_of[f]])
+                AMT_HIP(hipMemcpyAsync(res.buf[res_of[f]], src, n * sizeof(T), hipMemcpyHostToDevice, up));
+            continue;
+        }
         if (pack_small) memcpy(staged(dev[0][f]), src, n * sizeof(T));
         else AMT_HIP(hipMemcpyAsync(dev[0][f], src, n * sizeof(T), hipMemcpyHostToDevice, up));
     }
@@ -400,7 +593,7 @@ static int amt_host_call(const AmtArgs<T> &h)
         hipError_t e = hipStreamWaitEvent(down, ws.computed[s], 0);
         for (int f = 0; f < 26 && p.nk > 0 && e == hipSuccess; ++f) {
             const Item &it = items[f];
-            if (!it.out || it.rank != 3) continue;
+            if (!it.out || it.rank != 3 || res_of[f] >= 0) continue;   // deferred outputs stay on the device
             hipMemcpy3DParms cp;
             memset(&cp, 0, sizeof cp);
             cp.srcPtr = make_hipPitchedPtr(dev[s][f], (size_t)idim * sizeof(T), (size_t)idim, (size_t)kdim);
@@ -471,6 +664,13 @@ static int amt_host_call(const AmtArgs<T> &h)
             if (it.rank != 3 || !it.in) continue;
             if (f == F_WW) {                                  // level 1 only
                 const T *src = it.host + (size_t)(c0 - h.jms) * r3 + (size_t)p.k1 * idim;
+                if (res_of[f] >= 0) {                             // deferred: goes up only while the device copy is not valid
+                    if (res_upload[res_of[f]])
+                        AMT_HIP(hipMemcpy2DAsync(reinterpret_cast<T *>(res.buf[res_of[f]]) + (size_t)(c0 - (w.j_start - 1)) * r3 + (size_t)p.k1 * idim,
+                                                 r3 * sizeof(T), src, r3 * sizeof(T), (size_t)idim * sizeof(T), (size_t)(c1 - c0 + 1),
+                                                 hipMemcpyHostToDevice, up));
+                    continue;
+                }
                 T *dst = dev[s][f] + r3 + (size_t)p.k1 * idim;
                 if (pack_big)
                     for (int j = c0; j <= c1; ++j)
@@ -480,14 +680,24 @@ static int amt_host_call(const AmtArgs<T> &h)
                                              (size_t)(c1 - c0 + 1), hipMemcpyHostToDevice, up));
                 continue;
             }
-            const int lo = it.halo ? c0 - 1 : c0, hi = it.halo ? c1 + 1 : c1;
-            const size_t n = (size_t)(hi - lo + 1) * r3 * sizeof(T);
-            if (res_of[f] >= 0) {                             // resident: its rows go up only while it is stale
-                if (res_upload[res_of[f]])
-                    AMT_HIP(hipMemcpyAsync(reinterpret_cast<T *>(res.buf[res_of[f]]) + (size_t)(lo - (w.j_start - 1)) * r3,
-                                           it.host + (size_t)(lo - h.jms) * r3, n, hipMemcpyHostToDevice, up));
+            int lo = it.halo ? c0 - 1 : c0;
+            const int hi = it.halo ? c1 + 1 : c1;
+            if (res_of[f] >= 0) {
+                // kept: its rows go up only while the device copy is not valid, and every row ONCE per call -- a later chunk
+                // starts behind what the earlier ones uploaded (its lower halo rows are already there, and the kernel of the
+                // chunk before may be reading them: ADVICE r03)
+                const int r = res_of[f];
+                if (res_upload[r]) {
+                    if (lo <= res_hi[r]) lo = (int)res_hi[r] + 1;
+                    if (lo <= hi)
+                        AMT_HIP(hipMemcpyAsync(reinterpret_cast<T *>(res.buf[r]) + (size_t)(lo - (w.j_start - 1)) * r3,
+                                               it.host + (size_t)(lo - h.jms) * r3, (size_t)(hi - lo + 1) * r3 * sizeof(T),
+                                               hipMemcpyHostToDevice, up));
+                    res_hi[r] = hi;
+                }
                 continue;
             }
+            const size_t n = (size_t)(hi - lo + 1) * r3 * sizeof(T);
             if (pack_big) memcpy(staged(dev[s][f]) + (size_t)(lo - ja) * r3, it.host + (size_t)(lo - h.jms) * r3, n);
             else AMT_HIP(hipMemcpyAsync(dev[s][f] + (size_t)(lo - ja) * r3, it.host + (size_t)(lo - h.jms) * r3, n,
                                         hipMemcpyHostToDevice, up));
@@ -498,7 +708,8 @@ static int amt_host_call(const AmtArgs<T> &h)
         AmtArgs<T> d = h;
         T *q[26];
         for (int f = 0; f < 26; ++f)                          // every array as if it began at row ja
-            q[f] = items[f].rank == 2 ? dev[0][f] + (size_t)(ja - (w.j_start - 1)) * r2
+            q[f] = items[f].rank == 2 ? (res_of[f] >= 0 ? reinterpret_cast<T *>(res.buf[res_of[f]]) : dev[0][f]) + (size_t)(ja - (w.j_start - 1)) * r2
+                 : items[f].rank == 1 ? (res_of[f] >= 0 ? reinterpret_cast<T *>(res.buf[res_of[f]]) : dev[0][f])
                  : res_of[f] >= 0 ? reinterpret_cast<T *>(res.buf[res_of[f]]) + (size_t)(ja - (w.j_start - 1)) * r3 : dev[s][f];
         d.ww = q[0]; d.ww_1 = q[1]; d.u = q[2]; d.u_1 = q[3]; d.v = q[4]; d.v_1 = q[5]; d.mu = q[6];
         d.mut = q[7]; d.muave = q[8]; d.muts = q[9]; d.muu = q[10]; d.muv = q[11]; d.mudf = q[12];
@@ -535,7 +746,7 @@ static int amt_host_call(const AmtArgs<T> &h)
             AMT_HIP(hipStreamSynchronize(down));
             for (int f = 0; f < 26; ++f) {                    // scatter: the window's cells only
                 const Item &it = items[f];
-                if (!it.out) continue;
+                if (!it.out || res_of[f] >= 0) continue;      // deferred outputs stay on the device
                 if (it.rank == 2) {
                     for (int j = w.j_start; j <= w.j_end; ++j)
                         memcpy(const_cast<T *>(it.host) + (size_t)(j - h.jms) * r2 + p.i0,
@@ -552,7 +763,7 @@ static int amt_host_call(const AmtArgs<T> &h)
         } else {
             for (int f = 0; f < 26; ++f) {
                 const Item &it = items[f];
-                if (!it.out || it.rank != 2) continue;
+                if (!it.out || it.rank != 2 || res_of[f] >= 0) continue;
                 // the window's cells only (a strided copy): two host threads running tiles that split i
                 // must not rewrite each other's columns with what they uploaded
                 AMT_HIP(hipMemcpy2DAsync(const_cast<T *>(it.host) + (size_t)(w.j_start - h.jms) * r2 + p.i0, r2 * sizeof(T),
@@ -567,8 +778,15 @@ static int amt_host_call(const AmtArgs<T> &h)
         if (e != hipSuccess && rc == AMT_OK)
             rc = amt_fail(AMT_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
     }
-    if (res.enabled)
-        for (int r = 0; r < HostWorkspace::NRES; ++r) res.valid[r] = (rc == AMT_OK);
+    for (int r = 0; r < HostWorkspace::NKEEP; ++r) {
+        if (!res.active[r]) continue;
+        res.valid[r] = (rc == AMT_OK);
+        if (r >= HostWorkspace::NCACHE) {
+            // the device copy is the truth from here on (after a failed call nobody is: the host array goes up again)
+            res.stale[r] = (rc == AMT_OK);
+            if (rc == AMT_OK && res.check) amt_keep_canary(res, r, true);
+        }
+    }
     if (trace)
         fprintf(stderr, "amt one-shot: %d chunk(s) of %ld rows, 3-D %s%s, small arrays %s; alloc %.2f ms, enqueue %.2f ms, drain %.2f ms\n",
                 nchunk, rows, pinned ? "pinned" : pack_big ? "packed" : "pageable", threaded ? " + download thread" : "",

@@ -38,7 +38,7 @@ program advance_mu_t_driver
   real(c_float) :: ms
   integer(kind=8) :: c0, c1, cmid, hz
   real(kind=8) :: cells, secs
-  integer :: nbad
+  integer :: nbad, ndef
 
   ni = 64; nk = 40; nj = 64; nsweeps = 5; outdir = ' '; iflag = 0      ! BASELINE.json configs[0]
   if (command_argument_count() >= 3) then
@@ -182,6 +182,7 @@ program advance_mu_t_driver
   ! ---- the acoustic loop of one Runge-Kutta stage: the linearisation state ww_1, u_1, v_1, t_1 and the tendency
   !      ft do not change between the sub-steps, so with the residency cache on they are uploaded by the first call
   !      only (amt_host_invalidate(c_null_ptr) when the next stage has rewritten them).  Timing only, as above.
+  ww_r = ww; t_r = t; mu_r = mu                       ! the state this loop starts from (the deferred loop below repeats it)
   call amt_check(amt_host_cache_enable(1_c_int), 'amt_host_cache_enable')
   CALL advance_mu_t( ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,            &
                      t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,                     &
@@ -201,6 +202,43 @@ program advance_mu_t_driver
   secs = real(c1 - c0, 8) / real(hz, 8)
   print '(a,i0,a,f10.4,a,f12.1,a)', 'one-shot, pinned, constants resident: ', nsweeps, ' calls, ', secs * 1.0d3 / nsweeps, &
         ' ms/call,  ', cells * nsweeps / secs / 1.0d6, ' Mcells/s'
+  ! ---- the same loop with the OUTPUTS deferred as well (amt_host_defer): ww, t, t_ave, mu, muave, muts, mudf stay on the
+  !      device from sub-step to sub-step -- in WRF the next routine of the acoustic loop would take them there -- and come
+  !      down once, when the loop is over (amt_host_fetch); a sub-step then uploads u, v and the 2-D / 1-D inputs only.
+  !      Starts from the state the loop above started from and must end with its bits.
+  call swap3(ww, ww_r); call swap3(t, t_r); call swap2(mu, mu_r)
+  t_ave_r = t_ave; muave_r = muave; muts_r = muts; mudf_r = mudf
+  call amt_check(amt_host_defer(c_null_ptr, 1_c_int), 'amt_host_defer')
+  CALL advance_mu_t( ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,            &
+                     t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,                     &
+                     msfuy, msfvx_inv, msftx, msfty, config_flags,                                      &
+                     ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte )
+  call system_clock(count=c0)
+  block
+    integer :: s
+    do s = 1, nsweeps
+      CALL advance_mu_t( ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf, t, t_1,        &
+                         t_ave, ft, mu_tend, rdx, rdy, dts, epssm, dnw, fnm, fnp, rdnw,                 &
+                         msfuy, msfvx_inv, msftx, msfty, config_flags,                                  &
+                         ids, ide, jds, jde, kde, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte )
+    end do
+  end block
+  call system_clock(count=c1)
+  secs = real(c1 - c0, 8) / real(hz, 8)
+  print '(a,i0,a,f10.4,a,f12.1,a)', 'one-shot, pinned, constants resident, outputs deferred: ', nsweeps, ' calls, ', &
+        secs * 1.0d3 / nsweeps, ' ms/call,  ', cells * nsweeps / secs / 1.0d6, ' Mcells/s'
+  if (amt_host_stale(c_loc(t)) /= 1) error stop 3
+  call system_clock(count=c0)
+  call amt_check(amt_host_fetch(c_null_ptr), 'amt_host_fetch')
+  call system_clock(count=c1)
+  print '(a,f10.4,a)', 'amt_host_fetch of the seven outputs, once per loop: ', real(c1 - c0, 8) / real(hz, 8) * 1.0d3, ' ms'
+  if (amt_host_stale(c_null_ptr) /= 0) error stop 4
+  call amt_check(amt_host_defer(c_null_ptr, 0_c_int), 'amt_host_defer')
+  ndef = 0
+  ndef = ndef + count(transfer(ww, 1_1, size(ww) * storage_size(rdx) / 8) /= transfer(ww_r, 1_1, size(ww) * storage_size(rdx) / 8))
+  ndef = ndef + count(t /= t_r) + count(t_ave /= t_ave_r) + count(mu /= mu_r)
+  ndef = ndef + count(muave /= muave_r) + count(muts /= muts_r) + count(mudf /= mudf_r)
+  print '(a,i0)', 'deferred loop vs plain loop: differing elements = ', ndef
   call amt_check(amt_host_cache_enable(0_c_int), 'amt_host_cache_enable')
   call unpin3(ww); call unpin3(ww_1); call unpin3(u); call unpin3(u_1); call unpin3(v); call unpin3(v_1)
   call unpin3(t); call unpin3(t_1); call unpin3(t_ave); call unpin3(ft)
@@ -208,6 +246,7 @@ program advance_mu_t_driver
   ! ---- both paths must agree bit for bit (compared above, before the pinned timing run) ----
   print '(a,i0)', 'one-shot vs resident: differing elements = ', nbad
   if (nbad /= 0) error stop 2
+  if (ndef /= 0) error stop 5
 
 contains
 
@@ -243,6 +282,28 @@ contains
     integer(c_int), intent(in) :: field
     type(c_ptr), intent(in) :: host
     call amt_check(amt_domain_download(dom, field, host), 'amt_domain_download')
+  end subroutine
+  subroutine swap3(a, b)
+    real(wp), intent(inout) :: a(:,:,:), b(:,:,:)
+    real(wp) :: x
+    integer :: i, k, j
+    do j = 1, size(a, 3)
+      do k = 1, size(a, 2)
+        do i = 1, size(a, 1)
+          x = a(i, k, j); a(i, k, j) = b(i, k, j); b(i, k, j) = x
+        end do
+      end do
+    end do
+  end subroutine
+  subroutine swap2(a, b)
+    real(wp), intent(inout) :: a(:,:), b(:,:)
+    real(wp) :: x
+    integer :: i, j
+    do j = 1, size(a, 2)
+      do i = 1, size(a, 1)
+        x = a(i, j); a(i, j) = b(i, j); b(i, j) = x
+      end do
+    end do
   end subroutine
   subroutine pin3(a)
     real(wp), target, intent(inout) :: a(:,:,:)

@@ -78,6 +78,25 @@ MODULE amt_c_binding
          type(c_ptr), value :: ptr
          integer(c_int) :: rc
       end function
+      ! deferred outputs of the one-shot calls of this thread: ww, t, t_ave, mu, muave, muts, mudf (c_null_ptr: all) stay
+      ! on the device after a call until amt_host_fetch brings the window's cells down; amt_host_stale: 1 while the device
+      ! copy is newer than the host array
+      function amt_host_defer(ptr, on) bind(C, name="amt_host_defer") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: ptr
+         integer(c_int), value :: on
+         integer(c_int) :: rc
+      end function
+      function amt_host_fetch(ptr) bind(C, name="amt_host_fetch") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: ptr
+         integer(c_int) :: rc
+      end function
+      function amt_host_stale(ptr) bind(C, name="amt_host_stale") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: ptr
+         integer(c_int) :: rc
+      end function
 
       ! error text of the calling thread (NUL-terminated C string)
       function amt_last_error() bind(C, name="amt_last_error") result(msg)

@@ -77,6 +77,9 @@ SYMBOLS = {
     "amt_host_cache_enable": (_I, [_I]),
     "amt_host_cache_check": (_I, [_I]),
     "amt_host_invalidate": (_I, [_P]),
+    "amt_host_defer": (_I, [_P, _I]),
+    "amt_host_fetch": (_I, [_P]),
+    "amt_host_stale": (_I, [_P]),
     "amt_set_device": (_I, [_I]),
     "amt_comm_unique_id": (_I, [_P]),
     "amt_comm_rendezvous_file": (_I, [ctypes.c_char_p, ctypes.c_uint64, _I, _I, ctypes.c_double, _P]),
