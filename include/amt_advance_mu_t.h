@@ -329,6 +329,10 @@ int amt_slab_exchange(amt_slab *slab);       /* the halo exchange alone         
 int amt_slab_step(amt_slab *slab, int n_sweeps);             /* asynchronous                      */
 int amt_slab_step_timed(amt_slab *slab, int n_sweeps, float *ms_total);
 int amt_slab_sync(amt_slab *slab);
+/* Test hook: from now on every sweep's exchange starts `microseconds` late on the communication stream (a device-side
+ * delay in front of the ncclSend/ncclRecv group), i.e. the neighbours' rows arrive that much late -- neighbour skew on
+ * one GPU with the rank as its own neighbour (AMT_SLAB_LOOPBACK; profiles/slab_loopback.py --skew-us).  0 = off. */
+int amt_slab_set_skew_us(amt_slab *slab, int microseconds);
 long amt_slab_halo_bytes(const amt_slab *slab);              /* sent (= received) per sweep      */
 /* rank and size as the communicator reports them (0 of 1 without one) */
 int amt_slab_comm_info(const amt_slab *slab, int *rank, int *world);

@@ -1,6 +1,13 @@
 """One rank of N's j-slab on one GPU through the NATIVE stepper with RCCL in loopback (the rank is
 its own neighbour): what the exchange + the edge launches cost against the bare slab sweep.
-python profiles/slab_loopback.py [--nj 512] [--dtype f64]"""
+python profiles/slab_loopback.py [--nj 512] [--dtype f64] [--skew-us 0 100 500 1000 1500 2000 3000]
+
+--skew-us: the one thing loopback cannot show by itself is a neighbour that is LATE.  With a skew the exchange of every
+sweep starts that many microseconds late on the communication stream (amt_slab_set_skew_us: a device-side delay in front
+of the ncclSend/ncclRecv group), so this rank's halo rows arrive late while its interior rows compute: the sweep time
+against the skew shows how much skew the overlap absorbs (about the interior's run time minus exchange and edge rows)
+before it shows up one for one -- i.e. how far neighbours may drift apart before the single-buffered halo rows of
+DESIGN.md section 9.1 would need a second buffer."""
 import argparse
 import sys
 import time
@@ -18,6 +25,7 @@ ap.add_argument("--nk", type=int, default=60)
 ap.add_argument("--nj", type=int, default=512)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--sweeps", type=int, default=200)
+ap.add_argument("--skew-us", type=int, nargs="*", default=[])
 a = ap.parse_args()
 pkg = g.load_package()
 S = pkg.synth
@@ -45,3 +53,20 @@ for overlap in (True, False):
     print(f"  native stepper, RCCL loopback, {'overlap (interior || exchange + edges)' if overlap else 'no overlap (exchange, interior, edges)'}: "
           f"{ms:.4f} ms, halo bytes {st.halo_bytes_per_sweep()}")
     st.close()
+
+if a.skew_us:
+    print("skew of the neighbours' rows (us) -> ms per sweep, overlap on / off")
+    steppers = {ov: pkg.patch.NativeSlabStepper(dev, 0, 1, pkg.patch.NativeSlabStepper.comm_unique_id(), loopback=True, overlap=ov)
+                for ov in (True, False)}
+    for us in a.skew_us:
+        row = []
+        for ov in (True, False):
+            st = steppers[ov]
+            st.set_skew_us(us)
+            row.append(timed(lambda n: (st.step(n), st.sync()), max(20, a.sweeps // 4)))
+        print(f"  {us:6d} us: {row[0]:.4f} ms   {row[1]:.4f} ms   (exposed with overlap: {max(0.0, row[0] - base_overlap) * 1e3:.0f} us)"
+              if 'base_overlap' in dir() else f"  {us:6d} us: {row[0]:.4f} ms   {row[1]:.4f} ms")
+        if us == 0:
+            base_overlap = row[0]
+    for st in steppers.values():
+        st.close()

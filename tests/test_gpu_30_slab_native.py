@@ -297,3 +297,37 @@ def test_wrapped_domain_with_its_own_stream_and_the_reporting_calls(pkg, torch_m
         assert bits_equal(dev.arrays[n].cpu().numpy(), want.arrays[n].cpu().numpy()), n
     null = (ctypes.c_void_p * len(S.FIELD_NAMES))()
     assert L.amt_domain_wrap(ctypes.byref(h), 4, *cfg.as_ints(), *b.as_tuple(), null, None) == lib.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "no-overlap"])
+def test_neighbour_skew_delays_the_edges_not_the_bits(pkg, torch_mod, overlap):
+    """amt_slab_set_skew_us (profiles/slab_loopback.py --skew-us): the exchange of every sweep starts late on the
+    communication stream -- a neighbour that is behind.  The halo rows still arrive before the edge rows are computed
+    (poisoned halos, same bits as without skew), and the sweep takes longer by about the skew that the interior's
+    run time does not cover."""
+    import time
+    S = pkg.synth
+    gdims = (200, 12, 60)
+    gb = S.domain_bounds(*gdims, aligned=True)
+    b = S.slab_bounds(gb, 1, 3)
+    results, times = [], []
+    for skew in (0, 3000):
+        dev = S.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=31, global_dims=gdims, device="cuda:0")
+        for n in S.HALO_FROM_ABOVE:
+            dev.arrays[n][-1].fill_(float("nan"))
+        dev.arrays["t_1"][0].fill_(float("nan"))
+        torch_mod.cuda.synchronize()
+        st = pkg.patch.NativeSlabStepper(dev, 0, 1, pkg.patch.NativeSlabStepper.comm_unique_id(), loopback=True, overlap=overlap)
+        st.step(1)
+        st.sync()                                                  # connection set-up outside the timing
+        st.set_skew_us(skew)
+        t0 = time.perf_counter()
+        st.step(4)
+        st.sync()
+        times.append((time.perf_counter() - t0) / 4)
+        st.close()
+        results.append({n: dev.arrays[n].cpu().numpy() for n in S.OUTPUTS})
+    for n in S.OUTPUTS:
+        assert np.isfinite(results[1][n][1:-1]).all(), n
+        assert bits_equal(results[0][n], results[1][n]), n
+    assert times[1] > times[0] + 2.0e-3, times                     # a 3 ms skew on a 20 us slab shows up almost in full

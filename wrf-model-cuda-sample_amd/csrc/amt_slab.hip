@@ -259,6 +259,7 @@ struct amt_slab {
     hipStream_t comm_stream = nullptr;
     hipEvent_t inputs_final = nullptr, edges_done = nullptr, t0 = nullptr, t1 = nullptr;
     double *red = nullptr;               // one device double for amt_slab_barrier / amt_slab_max
+    int skew_us = 0;                     // test hook: the neighbours' rows arrive this late (amt_slab_set_skew_us)
 };
 
 extern "C" int amt_slab_destroy(amt_slab *s)
@@ -364,6 +365,14 @@ int amt_slab_enqueue_exchange(amt_slab *s, hipStream_t stream)
     return AMT_OK;
 }
 
+// Test hook (amt_slab_set_skew_us): holds the communication stream for `ticks` of the 100 MHz real-time counter, so that
+// the exchange behind it starts -- and the neighbours' rows arrive -- that much late: neighbour skew on one GPU.
+__global__ void amt_slab_delay_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 template <typename T>
 int amt_slab_tile(amt_slab *s, hipStream_t stream, int jts, int jte)
 {
@@ -411,6 +420,8 @@ int amt_slab_step_t(amt_slab *s, int n_sweeps)
             rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi);              // interior overlaps the exchange
             if (rc) { join(); return rc; }
         }
+        if (s->skew_us > 0)
+            hipLaunchKernelGGL(amt_slab_delay_kernel, dim3(1), dim3(1), 0, edge_stream, (unsigned long long)s->skew_us * 100ull);
         rc = amt_slab_enqueue_exchange(s, edge_stream);
         if (rc) { join(); return rc; }
         if (!s->overlap) {
@@ -468,6 +479,13 @@ extern "C" int amt_slab_step_timed(amt_slab *s, int n_sweeps, float *ms_total)
     float ms = 0.f;
     AMT_HIP(hipEventElapsedTime(&ms, s->t0, s->t1));
     if (ms_total) *ms_total = ms;
+    return AMT_OK;
+}
+
+extern "C" int amt_slab_set_skew_us(amt_slab *s, int microseconds)
+{
+    if (!s || microseconds < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad skew argument");
+    s->skew_us = microseconds;
     return AMT_OK;
 }
 

@@ -345,6 +345,10 @@ class NativeSlabStepper:
         with self._dev():
             self._lib.check(self.L.amt_slab_sync(self._slab))
 
+    def set_skew_us(self, microseconds: int):
+        """Test hook: every later sweep's exchange starts this late on the communication stream (neighbour skew)."""
+        self._lib.check(self.L.amt_slab_set_skew_us(self._slab, int(microseconds)))
+
     def halo_bytes_per_sweep(self) -> int:
         return 2 * int(self.L.amt_slab_halo_bytes(self._slab))       # sent + received
 
