@@ -269,6 +269,13 @@ int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,
 int amt_domain_step(amt_domain *d, int n_sweeps);
 /* same, bracketed by HIP events on the domain's stream; returns after completion */
 int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_total);
+/* Placement tuning (speed only; +-3 % of a sweep hang on which physical pages the driver hands out):
+ * allocates the handle's 26 arrays `tries` times, one set after the other (needs room for a second copy of the state;
+ * stops early when there is none), copies the current contents over, times two sweeps of the handle's own kernel on each
+ * set and keeps the fastest; every array holds afterwards what it held before the call.  ms_per_try (tries floats, or
+ * NULL) receives the sweep time of each set (0 for sets that were not tried).  Device pointers obtained from
+ * amt_domain_field_ptr before the call are no longer valid.  Not for wrapped domains (amt_domain_wrap). */
+int amt_domain_tune_placement(amt_domain *domain, int tries, float *ms_per_try);
 int amt_domain_sync(amt_domain *d);
 void *amt_domain_field_ptr(amt_domain *d, int field);   /* device pointer, NULL on error */
 void *amt_domain_stream(amt_domain *d);                 /* hipStream_t */

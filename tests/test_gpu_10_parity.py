@@ -381,6 +381,46 @@ def test_resident_domain_handle(pkg, oracle, torch_mod):
         lib.check(L.amt_domain_destroy(h))
 
 
+def test_placement_tuning_keeps_the_contents_and_a_working_handle(pkg, oracle, torch_mod):
+    """amt_domain_tune_placement: the handle's arrays are re-allocated a few times and the fastest set kept -- every array
+    must hold afterwards what it held before (inputs AND the in/out state the timed sweeps advanced), and the next
+    sweep must be the oracle's."""
+    import ctypes
+    from wrf_model_cuda_sample_amd import lib
+    L = pkg.load_library()
+    S = pkg.synth
+    b = S.domain_bounds(130, 20, 24, aligned=True)
+    cfg = pkg.GridConfig(specified=True)
+    h = ctypes.c_void_p()
+    lib.check(L.amt_domain_create(ctypes.byref(h), 8, *cfg.as_ints(), *b.as_tuple()))
+    try:
+        lib.check(L.amt_domain_fill_synthetic(h, 5, b.ims, b.kms - 1, b.jms, 132, 21, 26))
+        lib.check(L.amt_domain_sync(h))
+        want = S.make_patch(b, cfg, dtype=np.float64, seed=5)
+        before = {}
+        for n in S.FIELD_NAMES:
+            a = np.empty(b.shape(n), dtype=np.float64)
+            lib.check(L.amt_domain_download(h, S.FIELD_ID[n], a.ctypes.data_as(ctypes.c_void_p)))
+            before[n] = a
+            assert bits_equal(a, want.arrays[n]), n
+        ms = (ctypes.c_float * 4)()
+        lib.check(L.amt_domain_tune_placement(h, 4, ms))
+        assert ms[0] > 0 and all(m >= 0 for m in ms)
+        for n in S.FIELD_NAMES:
+            a = np.empty(b.shape(n), dtype=np.float64)
+            lib.check(L.amt_domain_download(h, S.FIELD_ID[n], a.ctypes.data_as(ctypes.c_void_p)))
+            assert bits_equal(a, before[n]), f"{n} changed by the tuning"
+        lib.check(L.amt_domain_step(h, 1))
+        lib.check(L.amt_domain_sync(h))
+        oracle.advance_mu_t(*want.args())
+        for n in S.OUTPUTS:
+            a = np.empty(b.shape(n), dtype=np.float64)
+            lib.check(L.amt_domain_download(h, S.FIELD_ID[n], a.ctypes.data_as(ctypes.c_void_p)))
+            assert bits_equal(a, want.arrays[n]), n
+    finally:
+        lib.check(L.amt_domain_destroy(h))
+
+
 def test_slab_stepper_single_rank_on_gpu(pkg, torch_mod):
     """world = 1 through the SlabStepper == a direct call (the N=1 bench path)."""
     S = pkg.synth

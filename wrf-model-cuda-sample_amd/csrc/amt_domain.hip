@@ -199,6 +199,84 @@ extern "C" int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_tota
     return AMT_OK;
 }
 
+// Placement tuning.  Where the driver puts an array's pages moves the sweep by up to +-3 % (same kernel, same virtual
+// layout, fresh physical pages: profiles/r03_placement.md); nothing below the page size matters, so it cannot be steered --
+// only sampled.  This samples it for the handle's own arrays: `tries` allocations of the whole state one after the other (at
+// most two resident at a time), the current contents copied over, one warm-up and two timed sweeps of the handle's own
+// kernel on each, the fastest kept.  The contents of every array are what they were before the call (the in/out and output
+// arrays the timed sweeps advanced are restored from a copy).  bench.py does the same with its torch-owned arrays
+// (--probe-placements); a C / Fortran host gets the same memory this way.
+extern "C" int amt_domain_tune_placement(amt_domain *d, int tries, float *ms_per_try)
+{
+    if (!d || tries < 1) return amt_fail(AMT_ERR_INVALID_ARG, "bad tuning argument");
+    if (!d->owns_fields) return amt_fail(AMT_ERR_INVALID_ARG, "amt_domain_tune_placement: the arrays belong to the caller (amt_domain_wrap)");
+    DeviceScope scope(d->device);
+    static const int mutated[] = {AMT_F_WW, AMT_F_T, AMT_F_T_AVE, AMT_F_MU, AMT_F_MUAVE, AMT_F_MUTS, AMT_F_MUDF};
+    auto bytes = [&](int f) { return d->count(f) * (size_t)d->dtype_bytes; };
+    auto time_current = [&](float *ms) -> int {
+        int rc = amt_domain_step(d, 1);
+        if (rc) return rc;
+        AMT_HIP(hipEventRecord(d->ev0, d->stream));
+        rc = amt_domain_step(d, 2);
+        if (rc) return rc;
+        AMT_HIP(hipEventRecord(d->ev1, d->stream));
+        AMT_HIP(hipEventSynchronize(d->ev1));
+        AMT_HIP(hipEventElapsedTime(ms, d->ev0, d->ev1));
+        *ms *= 0.5f;
+        return AMT_OK;
+    };
+    for (int k = 0; k < tries && ms_per_try; ++k) ms_per_try[k] = 0.f;
+    // what the timed sweeps overwrite, kept aside
+    void *keep[AMT_F_COUNT] = {};
+    auto free_set = [](void **set) { for (int f = 0; f < AMT_F_COUNT; ++f) if (set[f]) { (void)hipFree(set[f]); set[f] = nullptr; } };
+    for (int f : mutated) {
+        if (hipMalloc(&keep[f], bytes(f)) != hipSuccess) {
+            (void)hipGetLastError();
+            free_set(keep);
+            return amt_fail(AMT_ERR_ALLOC, "amt_domain_tune_placement: no room for a copy of the output arrays (nothing changed)");
+        }
+        AMT_HIP(hipMemcpyAsync(keep[f], d->field[f], bytes(f), hipMemcpyDeviceToDevice, d->stream));
+    }
+    float best = 0.f;
+    int rc = time_current(&best);
+    if (ms_per_try) ms_per_try[0] = best;
+    for (int k = 1; k < tries && rc == AMT_OK; ++k) {
+        void *spacer = nullptr;                                   // shifts what the next allocations get
+        if (hipMalloc(&spacer, ((size_t)k * 1237 + 311) << 20) != hipSuccess) { (void)hipGetLastError(); spacer = nullptr; }
+        void *cand[AMT_F_COUNT] = {};
+        bool ok = true;
+        for (int f = 0; f < AMT_F_COUNT && ok; ++f) ok = hipMalloc(&cand[f], bytes(f)) == hipSuccess;
+        if (spacer) (void)hipFree(spacer);
+        if (!ok) {                                                // a second copy of the state does not fit: keep what we have
+            (void)hipGetLastError();
+            free_set(cand);
+            break;
+        }
+        for (int f = 0; f < AMT_F_COUNT; ++f) {
+            const bool mut = keep[f] != nullptr;
+            (void)hipMemcpyAsync(cand[f], mut ? keep[f] : d->field[f], bytes(f), hipMemcpyDeviceToDevice, d->stream);
+        }
+        void *cur[AMT_F_COUNT];
+        memcpy(cur, d->field, sizeof cur);
+        memcpy(d->field, cand, sizeof cand);
+        float ms = 0.f;
+        rc = time_current(&ms);
+        if (ms_per_try) ms_per_try[k] = ms;
+        if (rc == AMT_OK && ms < best) {
+            best = ms;
+            free_set(cur);                                        // the candidate stays
+        } else {
+            memcpy(d->field, cur, sizeof cur);
+            free_set(cand);
+        }
+    }
+    for (int f : mutated)                                         // contents as they were before the call
+        (void)hipMemcpyAsync(d->field[f], keep[f], bytes(f), hipMemcpyDeviceToDevice, d->stream);
+    (void)hipStreamSynchronize(d->stream);
+    free_set(keep);
+    return rc;
+}
+
 extern "C" int amt_domain_sync(amt_domain *d)
 {
     if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");

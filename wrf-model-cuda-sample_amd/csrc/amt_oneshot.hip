@@ -425,10 +425,18 @@ static int amt_host_call(const AmtArgs<T> &h)
     bool pinned = true, pinned_small = true;                  // the 3-D arrays / the 2-D and 1-D ones
     for (const Item &it : items) (it.rank == 3 ? pinned : pinned_small) &= amt_is_pinned(it.host);
 
-    // chunking: ~320 MB of 3-D input per chunk (measured best at 1024x60x1024 fp64)
+    // 3-D arrays that are kept on the device between calls (cached inputs, deferred outputs: below) need no chunk buffers
+    bool keep_want[26] = {};
+    int nbig = 10;
+    for (int r = 0; r < HostWorkspace::NKEEP; ++r) {
+        const int f = kKeepField[r];
+        keep_want[f] = r < HostWorkspace::NCACHE ? tl_workspace.res.enabled : tl_workspace.res.deferred(items[f].host);
+        if (keep_want[f] && items[f].rank == 3) --nbig;
+    }
+    // chunking: ~320 MB of 3-D arrays per chunk (measured best at 1024x60x1024 fp64), counting the arrays that stream
     const char *env_rows = getenv("AMT_STREAM_ROWS");         // test/tuning knob: rows per chunk
     const bool may_thread = !pinned && amt_env_flag("AMT_STREAM_THREAD", 1);
-    long rows = env_rows ? atol(env_rows) : (pinned || may_thread) ? (long)((320u << 20) / (r3 * sizeof(T) * 10) + 1) : (long)nj;
+    long rows = env_rows ? atol(env_rows) : (pinned || may_thread) ? (long)((320u << 20) / (r3 * sizeof(T) * (size_t)(nbig > 0 ? nbig : 1)) + 1) : (long)nj;
     if (rows < 1) rows = 1;
     if (rows > nj) rows = nj;
     const int nchunk = (int)((nj + rows - 1) / rows);
@@ -440,7 +448,7 @@ static int amt_host_call(const AmtArgs<T> &h)
     // packing (see above): the small arrays when they are pageable, the 3-D ones too when they
     // are pageable, one chunk and small
     const size_t small_bytes = 12 * (r2 * wrow * sizeof(T) + 256) + 4 * (n1 * sizeof(T) + 256);
-    const size_t big_bytes = (size_t)nset * 10 * (r3 * crow * sizeof(T) + 256);
+    const size_t big_bytes = (size_t)nset * nbig * (r3 * crow * sizeof(T) + 256);
     const bool allow_pack = amt_env_flag("AMT_STREAM_PACK", 1) != 0;
     const bool pack_small = allow_pack && !pinned_small && small_bytes <= ((size_t)32 << 20);
     const bool pack_big = pack_small && !pinned && nchunk == 1 && big_bytes <= ((size_t)64 << 20);
@@ -468,7 +476,9 @@ static int amt_host_call(const AmtArgs<T> &h)
             const Item &it = items[f];
             const bool big = it.rank == 3;
             if (big != (pass < 2) || it.out != (pass == 1 || pass == 2)) continue;
-            if (big) {
+            if (big && keep_want[f]) {
+                dev[0][f] = dev[1][f] = nullptr;              // lives in its kept whole-window copy
+            } else if (big) {
                 for (int s = 0; s < nset; ++s) dev[s][f] = static_cast<T *>(ws.take(r3 * crow * sizeof(T)));
                 if (nset == 1) dev[1][f] = dev[0][f];
             } else {
@@ -489,7 +499,7 @@ static int amt_host_call(const AmtArgs<T> &h)
         bool want[HostWorkspace::NKEEP];
         bool any_want = false;
         for (int r = 0; r < HostWorkspace::NKEEP; ++r) {
-            want[r] = r < HostWorkspace::NCACHE ? res.enabled : res.deferred(items[kKeepField[r]].host);
+            want[r] = keep_want[kKeepField[r]];
             any_want = any_want || want[r];
         }
         const int key[16] = {(int)sizeof(T), h.ims, h.ime, h.kms, h.kme, h.jms, h.jme, w.j_start, w.j_end, p.i0, p.i1, p.nk, p.k1, device, 0, 0};

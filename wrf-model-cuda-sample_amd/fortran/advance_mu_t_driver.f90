@@ -9,8 +9,9 @@
 ! domain handle (device arrays kept across calls -- the kernel-only time the
 ! reference reports) and checks that both paths agree bit for bit.
 !
-!   advance_mu_t_driver [NI NK NJ [nsweeps [outdir [flags]]]]
+!   advance_mu_t_driver [NI NK NJ [nsweeps [outdir [flags [placements]]]]]
 !     flags: 0 none, 1 specified, 2 nested, 3 specified+periodic_x
+!     placements: > 1 samples that many allocations of the resident state and keeps the fastest (amt_domain_tune_placement)
 !   With outdir the 7 updated arrays are written there as raw native-endian
 !   streams <name>.bin for an external checker.
 program advance_mu_t_driver
@@ -38,7 +39,8 @@ program advance_mu_t_driver
   real(c_float) :: ms
   integer(kind=8) :: c0, c1, cmid, hz
   real(kind=8) :: cells, secs
-  integer :: nbad, ndef
+  integer :: nbad, ndef, ntune
+  real(c_float) :: tune_ms(8)
 
   ni = 64; nk = 40; nj = 64; nsweeps = 5; outdir = ' '; iflag = 0      ! BASELINE.json configs[0]
   if (command_argument_count() >= 3) then
@@ -52,6 +54,11 @@ program advance_mu_t_driver
   if (command_argument_count() >= 5) call get_command_argument(5, outdir)
   if (command_argument_count() >= 6) then
      call get_command_argument(6, arg); read (arg, *) iflag
+  end if
+  ntune = 0
+  if (command_argument_count() >= 7) then
+     call get_command_argument(7, arg); read (arg, *) ntune
+     ntune = min(ntune, 8)
   end if
   config_flags%specified  = (iflag == 1 .or. iflag == 3)
   config_flags%nested     = (iflag == 2)
@@ -109,6 +116,11 @@ program advance_mu_t_driver
   call up(AMT_F_MSFTX, c_loc(msftx)); call up(AMT_F_MSFTY, c_loc(msfty))
   call up(AMT_F_DNW, c_loc(dnw));   call up(AMT_F_FNM, c_loc(fnm));   call up(AMT_F_FNP, c_loc(fnp))
   call up(AMT_F_RDNW, c_loc(rdnw))
+  ! placement of the arrays' pages (+-3 % of a sweep, DESIGN.md section 4.2): sampled by the library, contents kept
+  if (ntune > 1) then
+     call amt_check(amt_domain_tune_placement(dom, int(ntune, c_int), tune_ms), 'amt_domain_tune_placement')
+     print '(a,i0,a,8f9.4)', 'placement tuning, ', ntune, ' allocations, ms/sweep each: ', tune_ms(1:ntune)
+  end if
   call amt_check(amt_domain_step_timed(dom, int(nsweeps, c_int), ms), 'amt_domain_step_timed')
   cells = real(ni, 8) * real(nk, 8) * real(nj, 8)
   print '(a,i0,a,f10.4,a,f12.1,a)', 'resident device path: ', nsweeps, ' sweeps, ', ms / nsweeps, &

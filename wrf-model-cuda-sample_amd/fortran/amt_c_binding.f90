@@ -148,6 +148,15 @@ MODULE amt_c_binding
          integer(c_int), value :: n_sweeps
          integer(c_int) :: rc
       end function
+      ! placement tuning: the handle's arrays allocated `tries` times, two sweeps timed on each set, the fastest kept;
+      ! contents unchanged; ms_per_try receives the sweep time of every set
+      function amt_domain_tune_placement(handle, tries, ms_per_try) bind(C, name="amt_domain_tune_placement") result(rc)
+         import :: c_ptr, c_int, c_float
+         type(c_ptr), value :: handle
+         integer(c_int), value :: tries
+         real(c_float) :: ms_per_try(*)
+         integer(c_int) :: rc
+      end function
       function amt_domain_step_timed(handle, n_sweeps, ms_total) bind(C, name="amt_domain_step_timed") result(rc)
          import :: c_ptr, c_int, c_float
          type(c_ptr), value :: handle
