@@ -790,11 +790,13 @@ static int amt_host_call(const AmtArgs<T> &h)
     }
     for (int r = 0; r < HostWorkspace::NKEEP; ++r) {
         if (!res.active[r]) continue;
-        res.valid[r] = (rc == AMT_OK);
-        if (r >= HostWorkspace::NCACHE) {
-            // the device copy is the truth from here on (after a failed call nobody is: the host array goes up again)
-            res.stale[r] = (rc == AMT_OK);
-            if (rc == AMT_OK && res.check) amt_keep_canary(res, r, true);
+        if (r < HostWorkspace::NCACHE) {
+            res.valid[r] = (rc == AMT_OK);                    // a cached input of a failed call simply goes up again
+        } else if (rc == AMT_OK) {
+            // the device copy is the truth from here on.  (After a FAILED call the flags stay as they were: what the device
+            // held before the call is still what amt_host_fetch brings down, if the failure left it intact.)
+            res.valid[r] = res.stale[r] = true;
+            if (res.check) amt_keep_canary(res, r, true);
         }
     }
     if (trace)
