@@ -52,7 +52,7 @@ def test_random_cases_match_oracle(pkg, oracle):
     from pathlib import Path
     rng = np.random.default_rng(SEED)
     S = pkg.synth
-    ran = {"march": 0, "column": 0, "oneshot": 0, "oneshot_cached": 0}
+    ran = {"march": 0, "column": 0, "oneshot": 0, "oneshot_cached": 0, "oneshot_deferred": 0}
     t_start = time.time()
     L = pkg.load_library()
     for case in range(N_CASES):
@@ -96,10 +96,27 @@ def test_random_cases_match_oracle(pkg, oracle):
             for n in S.FIELD_NAMES:
                 assert bits_equal(one.arrays[n], two.arrays[n]), f"{what}: cached one-shot, second sub-step, {n} differs"
             ran["oneshot_cached"] += 1
+        if case % 16 == 4:
+            # ... and with the outputs deferred as well (r04): two sub-steps, nothing comes down until the fetch; check mode
+            # on, so the host arrays hold NaN canaries in between and a silent host write would be refused
+            one, two = host.copy(), want.copy()
+            pkg.host_cache_enable(True, check=True)
+            pkg.host_defer(None, True)
+            try:
+                pkg.advance_mu_t(*one.args())
+                pkg.advance_mu_t(*one.args())
+                pkg.host_fetch(None)
+            finally:
+                pkg.host_defer(None, False)
+                pkg.host_cache_enable(False, check=False)
+            oracle.advance_mu_t(*two.args())
+            for n in S.FIELD_NAMES:
+                assert bits_equal(one.arrays[n], two.arrays[n]), f"{what}: deferred one-shot, second sub-step, {n} differs"
+            ran["oneshot_deferred"] += 1
     L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
     summary = {"seed": SEED, "cases": N_CASES, "wall_s": round(time.time() - t_start, 1), "ran": ran, "failures": 0,
                "what": "tests/test_gpu_12_random.py: random extents (to 700 columns, 300 levels), paddings, sub-tiles, flags, "
-                       "precisions; march (LDS-DMA / register flavour) and column kernels, one-shot, cached one-shot; "
+                       "precisions; march (LDS-DMA / register flavour) and column kernels, one-shot, cached and deferred one-shot; "
                        "bit-exact against the oracle"}
     print("random campaign:", json.dumps(summary))
     out = Path(__file__).resolve().parent.parent / "gpurun_out"
