@@ -41,3 +41,4 @@ for nj, n in ((2048, 2), (1024, 4), (512, 8)):
 json.dump(table, open(f"{here}/hbm_traffic.json", "w"), indent=1)
 PY
 cp profiles/hbm_traffic.json $O/hbm_traffic.json
+cp profiles/hbm_traffic.json $O/hbm_traffic.json
