@@ -83,6 +83,11 @@ static int amt_env_int(const char *name, int dflt)
 #ifndef AMT_NT_DMA
 #define AMT_NT_DMA 0    /* cache-policy bits of the bulk LDS-DMA loads (2 = nt) */
 #endif
+#ifndef AMT_P1_BATCH
+#define AMT_P1_BATCH -1 /* levels whose global loads P1 issues together before it consumes any: -1 the instantiation's own choice
+                           (amt_p1_batch), 1 level by level (what hipcc schedules on its own: it keeps register pressure low
+                           and pays one full memory latency per LEVEL), KPT all levels of the lane at once */
+#endif
 #ifndef AMT_CHAIN
 #define AMT_CHAIN 10    /* LDS reads kept in flight by the sequential k chains */
 #endif
@@ -260,6 +265,23 @@ __device__ __forceinline__ void amt_lds_barrier()
 // break the load batching) -- the LDS level buffers hold nkr = waves*LW rows either way.
 // WM: most waves a workgroup of this instantiation is launched with: 16 (4 per SIMD: 128 VGPRs per
 // lane) or 12 (3 per SIMD: 168 VGPRs -- what the shapes with level groups need to stay out of scratch).
+// Levels per load batch of P1 (see PB in the kernel).
+template <typename T, int VW, int KPT, int HL, int XD, bool DMA, int WM> constexpr int amt_p1_batch()
+{
+    if (AMT_P1_BATCH >= 0) return AMT_P1_BATCH > KPT ? KPT : AMT_P1_BATCH;
+    // As many levels as the instantiation's registers hold without scratch (a scratch reload drains the LDS-DMA like any
+    // load; `make check` fails the build on scratch in any selectable instantiation).  Measured, same process, same arrays
+    // (profiles/r04_raw/ab_p1_batch.txt): all three levels of the (.,3,.) shapes at once -1.4 % (fp32 8192x80x2048), -1.8 %
+    // (fp64 4096x80x2048), -0.7 / -1.6 % (40 levels fp64 / fp32); two of the four of <float,2,4,1> -0.4 % (fp32 4096x60x4096);
+    // the fp64 (1,4,.,16) shapes -- the headline among them -- and six levels per lane have no registers for it (a batch
+    // of two costs the headline 16-24 B of scratch and 0.8 %).
+    if (!DMA) return 1;
+    if (KPT <= 3) return KPT;
+    if (KPT == 4 && WM == 12) return 4;
+    if (KPT == 4 && sizeof(T) == 4 && VW == 2 && HL == 1) return 2;
+    return 1;
+}
+
 template <typename T, int VW, int KPT, int HL, int XD, bool FULL, bool DMA, int WM>
 __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p, const AmtMarchGrid g)
 {
@@ -437,13 +459,6 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             AMT_STAMP(2, 3);
             amt_lds_barrier();                                   // 2: DM published
             AMT_STAMP(2, 4);
-            if (any) {                                           // :151-157
-                const V mu_new = mu_old + dts * (dmdt + mu_tend);
-                amt_stv<T, VW>(mu_b, o2, mu_new, all, on);
-                amt_stv<T, VW>(mudf_b, o2, (dmdt + mu_tend), all, on);
-                amt_stv<T, VW>(muts_b, o2, mut_v + mu_new, all, on);
-                amt_stv<T, VW>(muave_b, o2, T(.5) * ((T(1.) + p.epssm) * mu_new + (T(1.) - p.epssm) * mu_old), all, on);
-            }
             AMT_STAMP(2, 5);
             amt_lds_barrier();                                   // 3: AB holds the increments
             AMT_STAMP(2, 6);
@@ -461,6 +476,18 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             }
             AMT_STAMP(2, 7);
             __syncthreads();                                     // 4: ww of the recurrence published (DMA landed)
+            // The 2-D mass update (:151-157) AFTER the second chain, although its inputs are ready since barrier 2: issued
+            // there, its four stores were the newest vector-memory operations of the wave when the chain loop began, and
+            // the loop's first LDS read into a register with a pending load waited vmcnt(0) -- for the stores' round trip
+            // to memory, on the critical path of every cell wave parked at barrier 4.  Here their round trip ends
+            // somewhere in the next row's P1.
+            if (any) {
+                const V mu_new = mu_old + dts * (dmdt + mu_tend);
+                amt_stv<T, VW>(mu_b, o2, mu_new, all, on);
+                amt_stv<T, VW>(mudf_b, o2, (dmdt + mu_tend), all, on);
+                amt_stv<T, VW>(muts_b, o2, mut_v + mu_new, all, on);
+                amt_stv<T, VW>(muave_b, o2, T(.5) * ((T(1.) + p.epssm) * mu_new + (T(1.) - p.epssm) * mu_old), all, on);
+            }
         }
     } else {
         // =====================================================================
@@ -671,8 +698,26 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                 // Neighbour columns c-1 and c+VW are read unclamped: for the tile's first / last lane they
                 // fall into the adjacent LDS row (always inside the LDS image) and the halo value is
                 // selected instead -- one address register serves all three reads.
+                // The global loads of P1 (what does not ride the LDS-DMA: v_1(j+1), u and u_1 at i and i+1), PB levels at a
+                // time: all loads of a batch are issued before any is consumed (the compiler barrier keeps them above the
+                // batch's LDS stores), so a batch pays ONE memory latency.  Left to itself hipcc interleaves load, wait and
+                // use level by level -- lowest register pressure, one full latency per level: four per row in the 60-level
+                // fp64 shape (ISA of r03: s_waitcnt vmcnt(0) after each level's three loads).
+                constexpr int PB = amt_p1_batch<T, VW, KPT, HL, XD, DMA, WM>();
+                V g_v1[KPT], g_uu[KPT], g_u1[KPT];
+                T g_un[KPT], g_u1n[KPT];
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
+                    if (PB > 1 && m % PB == 0) {
+#pragma unroll
+                        for (int q = m; q < m + PB && q < KPT; ++q) {
+                            const unsigned oq = o3 + lo(q);
+                            if (XD < 1) g_v1[q] = amt_ldv<T, VW>(v1_b + js, oq);
+                            if (XD < 2) { g_uu[q] = amt_ldv_stream<2, T, VW>(u_b, oq); g_un[q] = amt_ld_stream<2>(u_b + VW, oq); }
+                            if (XD < 3) { g_u1[q] = amt_ldv_stream<2, T, VW>(u1_b, oq); g_u1n[q] = amt_ld_stream<2>(u1_b + VW, oq); }
+                        }
+                        asm volatile("" ::: "memory");
+                    }
                     const unsigned om = o3 + lo(m);
                     const int K = kf + m;
                     V vn, v1n, t1n, uu, u1;
@@ -682,17 +727,19 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                         vn = amt_ldv<T, VW>(v_b + js, om); t1n = amt_ldv<T, VW>(t1_b + js, om);
                         amt_stsv<T, VW>(T1n + (kfw + m) * TC + lc, t1n);
                     }
-                    if (XD >= 1) v1n = amt_ldsv<T, VW>(V1 + (kfw + m) * TC + lc); else v1n = amt_ldv<T, VW>(v1_b + js, om);
+                    if (XD >= 1) v1n = amt_ldsv<T, VW>(V1 + (kfw + m) * TC + lc); else if (PB > 1) v1n = g_v1[m]; else v1n = amt_ldv<T, VW>(v1_b + js, om);
                     if (XD >= 2) {
                         uu = amt_ldsv<T, VW>(U + (kfw + m) * TC + lc);
                         const T in = U[(kfw + m) * TC + lc + VW];
                         un = (il == TI - 1) ? UH[kfw + m + lh] : in;
-                    } else { uu = amt_ldv_stream<2, T, VW>(u_b, om); un = amt_ld_stream<2>(u_b + VW, om); }
+                    } else if (PB > 1) { uu = g_uu[m]; un = g_un[m]; }
+                    else { uu = amt_ldv_stream<2, T, VW>(u_b, om); un = amt_ld_stream<2>(u_b + VW, om); }
                     if (XD >= 3) {
                         u1 = amt_ldsv<T, VW>(U1 + (kfw + m) * TC + lc);
                         const T in = U1[(kfw + m) * TC + lc + VW];
                         u1n = (il == TI - 1) ? UH[nkr + kfw + m + lh] : in;
-                    } else { u1 = amt_ldv_stream<2, T, VW>(u1_b, om); u1n = amt_ld_stream<2>(u1_b + VW, om); }
+                    } else if (PB > 1) { u1 = g_u1[m]; u1n = g_u1n[m]; }
+                    else { u1 = amt_ldv_stream<2, T, VW>(u1_b, om); u1n = amt_ld_stream<2>(u1_b + VW, om); }
                     const V t1c = amt_ldsv<T, VW>(T1c + (kfw + m) * TC + lc);
                     const T tl_in = (T1c + (kfw + m) * TC + lc)[-1], tr_in = T1c[(kfw + m) * TC + lc + VW];
                     const T tl = (il == 0) ? THc[(kfw + m) * 2 + 2 * lh] : tl_in;
@@ -871,7 +918,9 @@ static bool amt_march_shape_feasible(int wbytes, const AmtMarchShape &s, int nk)
     return amt_march_lds_bytes(wbytes, s, nk) <= 160 * 1024;
 }
 
-// Every instantiation the library carries.  X(T, VW, KPT, HL, XD, DMA, WM)
+// Every instantiation the library carries.  X(T, VW, KPT, HL, XD, DMA, WM)   (-DAMT_MARCH_SHAPES=... or -include: a short list for
+// ISA inspection builds)
+#ifndef AMT_MARCH_SHAPES
 #define AMT_MARCH_SHAPES(X)                                                                      \
     /* fp64: 4 levels per lane at 16 waves, up to 6 at 12 waves; 2 for nk <= 30 */               \
     X(double, 1, 2, 1, 0, true, 16) X(double, 1, 2, 1, 3, true, 16) X(double, 1, 2, 1, 0, false, 16)    \
@@ -900,6 +949,7 @@ static bool amt_march_shape_feasible(int wbytes, const AmtMarchShape &s, int nk)
     X(float, 2, 4, 4, 0, true, 16) X(float, 2, 4, 4, 0, false, 16)                               \
     X(float, 2, 4, 4, 0, true, 12) X(float, 2, 4, 4, 0, false, 12)                               \
     X(float, 2, 6, 4, 0, true, 12) X(float, 2, 6, 4, 0, false, 12)
+#endif
 
 template <typename T> struct AmtMarchEntry {
     AmtMarchShape shape;
