@@ -83,6 +83,10 @@ static int amt_env_int(const char *name, int dflt)
 #ifndef AMT_NT_DMA
 #define AMT_NT_DMA 0    /* cache-policy bits of the bulk LDS-DMA loads (2 = nt) */
 #endif
+#ifndef AMT_TAVE_EARLY
+#define AMT_TAVE_EARLY 1 /* t_ave = the row's incoming t (:211) is stored between barriers 3 and 4, while the column wave runs
+                            its second chain and the cell waves would only wait: the one store of P3 that depends on neither chain */
+#endif
 #ifndef AMT_P1_BATCH
 #define AMT_P1_BATCH -1 /* levels whose global loads P1 issues together before it consumes any: -1 the instantiation's own choice
                            (amt_p1_batch), 1 level by level (what hipcc schedules on its own: it keeps register pressure low
@@ -644,6 +648,22 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
 #pragma unroll
         for (int m = 0; m < KPT; ++m) { vfm[m] = V(T(0)); vft[m] = V(T(0)); }
 
+        // P1's global loads of a batch of levels (amt_p1_batch).  (Issuing the whole lane's batch one row ahead, right behind
+        // barrier 4 and ahead of P3's stores, was built as well: 1-2 % SLOWER on every shape -- profiles/r04_80level.md.)
+        constexpr int PB = amt_p1_batch<T, VW, KPT, HL, XD, DMA, WM>();
+        V g_v1[KPT], g_uu[KPT], g_u1[KPT];
+        T g_un[KPT], g_u1n[KPT];
+        auto p1_loads = [&](int m0, int m1, unsigned orow) {     // orow: per-lane byte offset of the row (lane part included)
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                if (q < m0 || q >= m1) continue;
+                const unsigned oq = orow + lo(q);
+                if (XD < 1) g_v1[q] = amt_ldv<T, VW>(v1_b + js, oq);
+                if (XD < 2) { g_uu[q] = amt_ldv_stream<2, T, VW>(u_b, oq); g_un[q] = amt_ld_stream<2>(u_b + VW, oq); }
+                if (XD < 3) { g_u1[q] = amt_ldv_stream<2, T, VW>(u1_b, oq); g_u1n[q] = amt_ld_stream<2>(u1_b + VW, oq); }
+            }
+        };
+
         // ---- prologue: everything P1 of row ja needs; j-face fluxes of row ja ----
         if (DMA) {
             dma_rows(lane, t1_b, 0, T1);
@@ -703,19 +723,10 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                 // batch's LDS stores), so a batch pays ONE memory latency.  Left to itself hipcc interleaves load, wait and
                 // use level by level -- lowest register pressure, one full latency per level: four per row in the 60-level
                 // fp64 shape (ISA of r03: s_waitcnt vmcnt(0) after each level's three loads).
-                constexpr int PB = amt_p1_batch<T, VW, KPT, HL, XD, DMA, WM>();
-                V g_v1[KPT], g_uu[KPT], g_u1[KPT];
-                T g_un[KPT], g_u1n[KPT];
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
                     if (PB > 1 && m % PB == 0) {
-#pragma unroll
-                        for (int q = m; q < m + PB && q < KPT; ++q) {
-                            const unsigned oq = o3 + lo(q);
-                            if (XD < 1) g_v1[q] = amt_ldv<T, VW>(v1_b + js, oq);
-                            if (XD < 2) { g_uu[q] = amt_ldv_stream<2, T, VW>(u_b, oq); g_un[q] = amt_ld_stream<2>(u_b + VW, oq); }
-                            if (XD < 3) { g_u1[q] = amt_ldv_stream<2, T, VW>(u1_b, oq); g_u1n[q] = amt_ld_stream<2>(u1_b + VW, oq); }
-                        }
+                        p1_loads(m, m + PB, o3);
                         asm volatile("" ::: "memory");
                     }
                     const unsigned om = o3 + lo(m);
@@ -812,6 +823,18 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             }
             AMT_STAMP(stamp_slot, 5);
             amt_lds_barrier();                                       // 3: AB holds the increments
+            if (AMT_TAVE_EARLY && act) {
+                // :211  t_ave = t as it came in.  Of P3's three stores per level this one waits for no chain, only for its own
+                // load (issued behind barrier 1): it goes out here, under the second chain, and P3 keeps two stores per level
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    const bool real = FULL || kf + m < nk;
+                    bool onr[VW];
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) onr[e] = on[e] && real;
+                    amt_stv<T, VW>(tave_b, o3 + lo(m), told[m], all && real, onr);
+                }
+            }
             __syncthreads();                                         // 4: ww of the recurrence published; DMA landed
             AMT_STAMP(stamp_slot, 6);
 
@@ -837,7 +860,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                     if (m + 1 < KPT) wd_n = (wwu_n - w1[m + 1 < KPT ? m + 1 : 0]) * tw[m + 1 < KPT ? m + 1 : 0];
                     else if (has_above) wd_n = (wwu_n - w1_above) * amt_ldsv<T, VW>(TWB + (par * nc * HL + w * HL + 1) * TC + lane * VW);
                     if (!FULL && K + 1 >= nk) wd_n = V(T(0));        // wdtn(kde) = 0, :221
-                    amt_stv<T, VW>(tave_b, om, told[m], allr, onr);  // :211
+                    if (!AMT_TAVE_EARLY) amt_stv<T, VW>(tave_b, om, told[m], allr, onr);  // :211 (stored under the second chain otherwise)
                     const V tb = told[m] + msfty * dts * ftk[m];     // :212
                     amt_stv<T, VW>(t_b, om, tb - dts * msfty * ( hf[m] + S1[4 * (kfw + m) + 4 * lh + 3] * (wd_n - wd_k) ), allr, onr);   // :237-246
                     wwu = wwu_n; wd_k = wd_n;
