@@ -30,11 +30,14 @@
 //      column wave  dmdt = sum_k dnw(k)*AB[k] in the Fortran's sequential k order -> DM[col]
 //      -- barrier 2 --
 //      cell waves   AB[k][col] <- dnw(k)*(dmdt+dvdxi(k)+mu_tend)/msfty  (:161, one divide
-//                   per cell, own slots); column wave: the 2-D mass update (:151-157)
+//                   per cell, own slots)
 //      -- barrier 3 --
 //      column wave  AB[k] <- ww(k); ww(k+1) = ww(k) - AB[k], sequential  (:161)
+//      cell waves   store t_ave = t as it came in (:211): the one store that waits for no chain
 //      -- barrier 4 --
-//      cell waves   ww - ww_1 (:170), wdtn (:220-227), theta update (:211-212, :237-246)
+//      cell waves   ww - ww_1 (:170), wdtn (:220-227), theta update (:212, :237-246)
+//      column wave  the 2-D mass update (:151-157) -- behind the chain, not in front of it: its
+//                   stores' round trip to memory must not sit on the row's critical path
 //    A column's chains are summed exactly once, in order: bit-exact and no redundant LDS
 //    traffic (an earlier version let every wave redo both chains: LDS-bandwidth bound).
 //  * Level counts that do not fill the cell waves: the missing levels of the last wave are
