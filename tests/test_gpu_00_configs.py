@@ -152,8 +152,11 @@ def test_configs2_and_3_4096x60x4096_fp64_resident(pkg, oracle, torch_mod):
     m = re.search(r"jrows=(\d+)", label)
     jrows = int(m.group(1)) if m else 64
     rows = 64
-    seam = 2 + jrows * ((dims[2] // jrows) // 2)                         # a j-block boundary near the middle
-    starts = [1, dims[2] - rows + 1, seam - rows // 2, 2 + jrows * 5 - rows // 2]
+    nblk = -(-(dims[2] - 2) // jrows)                                    # blocks of jrows rows from row 2 (specified)
+    seams = [2 + jrows * k for k in sorted({1, nblk // 2, nblk - 1}) if 1 <= k < nblk]   # j-block boundaries
+    starts = [1, dims[2] - rows + 1] + [s_ - rows // 2 for s_ in seams]
+    if len(starts) < 4:
+        starts.append(dims[2] // 3)
     checked = _check_rows_against_oracle(pkg, oracle, dev, b, cfg, dims, np.float64, seed, starts, rows)
     assert len(checked) >= 0.05 * dims[2], len(checked)
     # configs[3]: j-slabs of eight ranks
@@ -196,8 +199,9 @@ def test_configs4_8192x80x8192_fp32_resident(pkg, oracle, torch_mod):
     m = re.search(r"jrows=(\d+)", label)
     jrows = int(m.group(1)) if m else 64
     rows = 64
-    nblk = dims[2] // jrows
-    seams = [2 + jrows * k for k in (1, nblk // 4, nblk // 2, (3 * nblk) // 4, nblk - 2)]
+    nblk = -(-(dims[2] - 2) // jrows)
+    seams = [2 + jrows * k for k in sorted({1, nblk // 4, nblk // 2, (3 * nblk) // 4, nblk - 2}) if 1 <= k < nblk]
+    assert len(seams) == 5, (label, seams)
     starts = [1, dims[2] - rows + 1] + [s - rows // 2 for s in seams]
     checked = _check_rows_against_oracle(pkg, oracle, dev, b, cfg, dims, np.float32, seed, starts, rows,
                                          also_fp64=(starts[0], starts[3]))

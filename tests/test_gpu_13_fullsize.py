@@ -81,8 +81,12 @@ def test_tenth_of_the_rows_of_configs2_against_the_oracle(pkg, oracle):
     # a workgroup's block come out of its prologue, the last ones end its march)
     first_row = 2                                              # specified: j_start = jds + 1
     nblk = -(-(dims[2] - 2) // jrows)                           # uniform blocks of jrows rows from first_row
-    bnd = [first_row + jrows * k for k in sorted({1, nblk // 6, nblk // 3, nblk // 2, (2 * nblk) // 3, nblk - 2})]
+    bnd = [first_row + jrows * k for k in sorted({1, nblk // 6, nblk // 3, nblk // 2, (2 * nblk) // 3, nblk - 2, nblk - 1}) if 1 <= k < nblk]
     starts = [1, dims[2] - rows + 1] + [x - rows // 2 for x in bnd if x + rows // 2 <= dims[2]]
+    k = 0
+    while len(starts) < 7:                                     # one-round launches have few block boundaries: add block interiors
+        starts.append(first_row + jrows * k + jrows // 2)
+        k += 1
     threads = _granted_cores(rows)
     checked = set()
     for jlo in starts:

@@ -1,0 +1,48 @@
+"""The launcher's rows-per-workgroup rule (host arithmetic of the HIP library, no GPU): amt_march_rows_for
+against a brute-force restatement of the rule in DESIGN.md section 4.2 -- minimise rounds(r) * (r + 0.5), blocks of
+more than 128 rows only when the whole launch is one round, never more rows than the 32-bit offsets span."""
+import math
+import random
+
+import pytest
+
+
+def _rule(ntile, nj, cus, max_rows):
+    best, pick = None, 1
+    for r in range(1, min(nj, max_rows) + 1):
+        blocks = ntile * math.ceil(nj / r)
+        rounds = math.ceil(blocks / cus)
+        if rounds > 1 and r > 128:
+            continue
+        cost = rounds * (r + 0.5)
+        if best is None or cost < best - 1e-9 or (cost < best + 1e-9 and r > pick):
+            best, pick = cost, r
+    return pick
+
+
+@pytest.fixture(scope="module")
+def L(pkg):
+    return pkg.load_library()
+
+
+def test_rows_of_the_baseline_configs(L):
+    # (tiles, rows, CUs, rows the offsets span) -> rows per workgroup
+    assert L.amt_march_rows_for(64, 4094, 256, 1070) == 1024      # configs[2] 4096x60x4096 fp64: 256 blocks, one round
+    assert L.amt_march_rows_for(64, 510, 256, 1070) == 128        # configs[3] one j-slab of eight: one round
+    assert L.amt_march_rows_for(128, 8190, 256, 806) == 128       # configs[4] 8192x80x8192 fp32: 32 rounds
+    assert L.amt_march_rows_for(8, 510, 256, 9999) == 16          # configs[1] 512x60x512: 256 blocks of 16 rows
+    assert L.amt_march_rows_for(1, 64, 256, 9999) == 1            # one tile: a block per row
+
+
+def test_rows_rule_against_brute_force(L):
+    rng = random.Random(20260404)
+    for _ in range(400):
+        ntile = rng.choice([1, 2, 3, 8, 16, 31, 32, 64, 65, 100, 128, 257])
+        nj = rng.choice([1, 2, 7, 63, 64, 65, 200, 510, 512, 1000, 2046, 4094, 8190, rng.randint(1, 9000)])
+        cus = rng.choice([256, 304, 64, 8])
+        max_rows = rng.choice([3, 100, 806, 1070, 100000])
+        got = L.amt_march_rows_for(ntile, nj, cus, max_rows)
+        assert got == _rule(ntile, nj, cus, max_rows), (ntile, nj, cus, max_rows)
+        assert 1 <= got <= min(nj, max_rows)
+        if got > 128:
+            assert ntile * math.ceil(nj / got) <= cus

@@ -105,6 +105,7 @@ struct AmtMarchGrid {
     int jstep;       // rows from one j block's first row to the next one's (jrows; edge launches: j1 - j0)
     int njblk;       // number of j blocks
     int nwg;         // ntile_i * njblk
+    int xchunk;      // consecutive logical ids an XCD takes per round of the launch (0: one run for the whole launch)
 };
 
 // ---------------------------------------------------------------------------
@@ -249,8 +250,22 @@ extern "C" int amt_diag_stamps(void *out, int bytes)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(amt_stamp_buf), (size_t)bytes < sizeof amt_stamp_buf ? (size_t)bytes : sizeof amt_stamp_buf);
 }
+// every workgroup: REFCLK (100 MHz, one clock for the whole chip) when its first wave starts and when that wave leaves its last row,
+// and where it ran (HW_ID, XCC_ID) -- profiles/spans.py
+__device__ unsigned long long amt_span_buf[16384][4];
+#define AMT_SPAN(n) do { if (threadIdx.x == 0 && lid < 16384) { unsigned long long t_;                                 \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                              \
+        amt_span_buf[lid][n] = t_;                                                                                     \
+        if (n == 0) { unsigned h_, x_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h_));                \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x_));                                          \
+            amt_span_buf[lid][2] = h_; amt_span_buf[lid][3] = x_; } } } while (0)
+extern "C" int amt_diag_spans(void *out, int bytes)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(amt_span_buf), (size_t)bytes < sizeof amt_span_buf ? (size_t)bytes : sizeof amt_span_buf);
+}
 #else
 #define AMT_STAMP(slot, n) do { } while (0)
+#define AMT_SPAN(n) do { } while (0)
 #endif
 
 constexpr int AMT_N2D = 7;    // staged 2-D rows: msftx msfty muu msfuy muv' msfvx_inv' mu_tend
@@ -334,9 +349,16 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
     // dispatch), so give each XCD a contiguous run of logical ids: neighbouring i-tiles
     // of one j block then run on one XCD at about the same time and share the tile-edge
     // cache lines in that XCD's L2.  Speed only, never correctness.
-    const int nx = 8, q = g.nwg / nx, r = g.nwg % nx;
+    const int nx = 8;
     const int x = blockIdx.x % nx, y = blockIdx.x / nx;
-    const int lid = x * q + (x < r ? x : r) + y;      // XCD x owns q (+1 if x < r) consecutive ids
+    const int xc = g.xchunk, whole = xc > 0 ? g.nwg / (nx * xc) : 0;          // whole rounds of nx * xc workgroups
+    int lid;
+    if (y < whole * xc) {
+        lid = (y / xc) * (nx * xc) + x * xc + y % xc;                         // round, then XCD x's run of xc ids in it
+    } else {
+        const int base = whole * nx * xc, rest = g.nwg - base, q = rest / nx, r = rest % nx;
+        lid = base + x * q + (x < r ? x : r) + (y - whole * xc);              // XCD x owns q (+1 if x < r) consecutive ids
+    }
     const int ja = p.j0 + (lid / g.ntile_i) * g.jstep;
     const int jb = (ja + g.jrows - 1 < p.j1) ? ja + g.jrows - 1 : p.j1;
     // Tiles are anchored at the WINDOW (its first column rounded down to a 128-byte line of the row), not
@@ -344,6 +366,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
     // layout) would otherwise straddle one more, half-empty tile (512x60x512: 9 x 27 = 243 workgroups on
     // 256 CUs instead of 8 x 32).  Neither the LDS-DMA nor the plain loads need more than line alignment.
     const int col0 = g.col_lo + (lid % g.ntile_i) * TC;
+    AMT_SPAN(0);
 #if AMT_STAMPS
     const bool stamp_on = (lid == g.nwg / 2 + g.ntile_i / 2) && (w == 0 || w >= nc - 1);
     const int stamp_slot = w == 0 ? 0 : colw ? 2 : 1;
@@ -874,6 +897,7 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
             // flavour -- the T1/TH buffer that was READ in this row's P1) is read by no other wave
             // before barrier 1 of the next row.
         }
+        AMT_SPAN(1);
     }
 }
 
@@ -1028,9 +1052,9 @@ template <typename T> static AmtMarchEntry<T> *amt_march_find(const AmtMarchShap
 // time through amt_march_force_shape -- tuning, A/B timing in one process and the parity tests
 // that walk every instantiation; 0 / -1 leave a parameter to the launcher.
 struct AmtMarchEnv {
-    int dma, kpt, hl, vw, xd, jrows, verbose, wm;
+    int dma, kpt, hl, vw, xd, jrows, verbose, wm, xchunk;
 };
-static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0};
+static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 0};
 // The instantiation the last plan of the calling thread chose (diagnosis / tests): "" before any launch.
 static thread_local char g_march_last[360] = "";
 extern "C" const char *amt_march_last_kernel(void) { return g_march_last; }
@@ -1043,7 +1067,8 @@ static const AmtMarchEnv &amt_march_env()
         g_march_env = {amt_env_int("AMT_MARCH_DMA", 1), amt_env_int("AMT_MARCH_KPT", 0),
                        amt_env_int("AMT_MARCH_HL", 0), amt_env_int("AMT_MARCH_VW", 0),
                        amt_env_int("AMT_MARCH_XD", -1), amt_env_int("AMT_MARCH_JROWS", 0),
-                       amt_env_int("AMT_MARCH_VERBOSE", 0), amt_env_int("AMT_MARCH_WM", 0)};
+                       amt_env_int("AMT_MARCH_VERBOSE", 0), amt_env_int("AMT_MARCH_WM", 0),
+                       amt_env_int("AMT_MARCH_XCHUNK", 0)};
     });
     return g_march_env;
 }
@@ -1062,27 +1087,58 @@ extern "C" int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, i
     return 0;
 }
 
+extern "C" int amt_march_set_xchunk(int xchunk)
+{
+    (void)amt_march_env();
+    g_march_env.xchunk = xchunk > 0 ? xchunk : 0;
+    ++g_march_generation;
+    return 0;
+}
+
+template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
+{
+    // the per-lane byte offsets of the march are 32-bit
+    const long row_bytes = p.jstride * (long)sizeof(T);
+    if (row_bytes <= 0) return 1L << 30;             // no rows to step over (a shape query without a domain)
+    return ((1L << 31) - 40L * p.idim * (long)sizeof(T)) / row_bytes - 3;
+}
+
 // Rows per workgroup.  A block costs its rows plus a prologue (4 extra array-rows of loads, about
 // half a row of time); workgroups run in rounds of one per CU (two small workgroups that share a CU
 // each run slower than one with twice the rows: 128x60x128 fp64 28 us against 23), so the sweep takes
-// about  rounds(r) * (r + 0.5)  row-times.  The r that minimises it: for the whole 4096-row domain any
-// r near 32 is within 1 %, but for a 510-row j-slab (8 GPUs) r = 32 would leave the last round 6 %
-// full (1040 workgroups on 256 CUs) and cost 17 % more than r = 11.  Small launches get short blocks,
-// down to one row (more workgroups: 64x40x64 takes 12 us with r = 1, 27 us with r = 4).
-static int amt_march_rows(long ntile_i, int nj, int cus, double *cost_out, long *rounds_out)
+// about  rounds(r) * (r + 0.5)  row-times.  The r that minimises it: for a 510-row j-slab (8 GPUs)
+// r = 32 would leave the last round 6 % full (1040 workgroups on 256 CUs) and cost 17 % more than
+// r = 11.  Small launches get short blocks, down to one row (more workgroups: 64x40x64 takes 12 us
+// with r = 1, 27 us with r = 4).
+// How long a block may be (profiles/r04_rows.md): in a launch of several rounds the CUs drift apart
+// by about 1 % (which XCD, which placement of the arrays) and the launch ends with its slowest CU, a
+// tail that grows with the block: up to 128 rows the saved prologues win (-0.3 .. -0.6 % against 64
+// rows), 256 rows and more lose where the launch still has rounds (4096x80x2048 fp64 +2 %).  A launch
+// that is ONE round -- as many blocks as CUs, each as long as it takes -- has no round to wait for and
+// 1/16 of the prologues: 4096x60x4096 fp64 1024 rows -1.0 .. -2.3 %, 4096x60x512 128 rows -2.8 .. -3.5 %.
+// `max_rows`: what the 32-bit row offsets of a block can span.
+static const int kAmtRowsPerBlockInRounds = 128;
+static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, double *cost_out, long *rounds_out)
 {
     double best = 1e300;
     int jrows = 1;
     long brounds = 1;
-    for (int r = 1; r <= 64 && r <= nj; ++r) {
+    for (int r = 1; r <= nj && r <= max_rows; ++r) {
         const long blocks = ntile_i * ((nj + r - 1) / r);
         const long rounds = (blocks + cus - 1) / cus;
+        if (rounds > 1 && r > kAmtRowsPerBlockInRounds) continue;
         const double cost = (double)rounds * (r + 0.5);
         if (cost < best - 1e-9 || (cost < best + 1e-9 && r > jrows)) { best = cost; jrows = r; brounds = rounds; }
     }
     if (cost_out) *cost_out = best;
     if (rounds_out) *rounds_out = brounds;
     return jrows;
+}
+
+// the row-count rule alone, for the host-logic tests (tests/test_march_rows.py)
+extern "C" int amt_march_rows_for(long ntile_i, int nj, int cus, long max_rows)
+{
+    return amt_march_rows(ntile_i, nj, cus, max_rows, nullptr, nullptr);
 }
 
 // Shape preference.  Measured (profiles/r02_shapes.md): most waves to hide latency and fewest
@@ -1174,7 +1230,7 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
                 const int tc = (64 / q.hl) * q.vw;
                 double c = 0;
                 long rounds = 1;
-                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, &c, &rounds);
+                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, amt_march_max_rows(p), &c, &rounds);
                 return c * (q.hl == out.hl ? 1.0 : rounds == 1 ? 0.8 : 1.2);
             };
             if (out.hl < 4)
@@ -1189,13 +1245,6 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
         return true;
     }
     return false;
-}
-
-template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
-{
-    // the per-lane byte offsets of the march are 32-bit
-    const long row_bytes = p.jstride * (long)sizeof(T);
-    return ((1L << 31) - 40L * p.idim * (long)sizeof(T)) / row_bytes - 3;
 }
 
 // What a launch needs beyond the pointers, cached per calling thread for the shape of the call
@@ -1248,7 +1297,7 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
     g.col_lo = amt_march_col_lo(p);
     g.ntile_i = (p.i1 - g.col_lo) / tc + 1;
     int jrows = env.jrows;
-    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), nullptr, nullptr);
+    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), max_rows, nullptr, nullptr);
     if (jrows > nj) jrows = nj;
     if (jrows > max_rows) jrows = (int)max_rows;
     g.jrows = jrows;
@@ -1260,6 +1309,7 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
         g.njblk = 2;
     }
     g.nwg = g.ntile_i * g.njblk;
+    g.xchunk = env.xchunk > 0 ? env.xchunk : 0;
     if (pl.lds > 64 * 1024) {
         // the attribute is per device and per kernel instantiation: allow all of the CU's LDS once
         // (what a launch occupies is its own dynamic size, not this ceiling); one-shot calls plan from
