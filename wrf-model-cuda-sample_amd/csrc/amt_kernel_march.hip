@@ -1116,9 +1116,12 @@ template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
 // rows), 256 rows and more lose where the launch still has rounds (4096x80x2048 fp64 +2 %).  A launch
 // that is ONE round -- as many blocks as CUs, each as long as it takes -- has no round to wait for and
 // 1/16 of the prologues: 4096x60x4096 fp64 1024 rows -1.0 .. -2.3 %, 4096x60x512 128 rows -2.8 .. -3.5 %.
+// The fp64 shapes with level groups (32-column tiles) stay at 64 rows in rounds: with 128 the launch takes the same
+// time (4096x80x2048: +0.5 / +0.2 / -0.1 % on three placements) and reads 1.8 % more (46.19 against 45.37 GB: neighbouring
+// tiles drift apart and lose each other's halo lines in L2).
 // `max_rows`: what the 32-bit row offsets of a block can span.
-static const int kAmtRowsPerBlockInRounds = 128;
-static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, double *cost_out, long *rounds_out)
+static int amt_march_rows_in_rounds(int wbytes, int hl) { return (wbytes == 8 && hl >= 2) ? 64 : 128; }
+static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, int rows_in_rounds, double *cost_out, long *rounds_out)
 {
     double best = 1e300;
     int jrows = 1;
@@ -1126,7 +1129,7 @@ static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, double *
     for (int r = 1; r <= nj && r <= max_rows; ++r) {
         const long blocks = ntile_i * ((nj + r - 1) / r);
         const long rounds = (blocks + cus - 1) / cus;
-        if (rounds > 1 && r > kAmtRowsPerBlockInRounds) continue;
+        if (rounds > 1 && r > rows_in_rounds) continue;
         const double cost = (double)rounds * (r + 0.5);
         if (cost < best - 1e-9 || (cost < best + 1e-9 && r > jrows)) { best = cost; jrows = r; brounds = rounds; }
     }
@@ -1136,9 +1139,9 @@ static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, double *
 }
 
 // the row-count rule alone, for the host-logic tests (tests/test_march_rows.py)
-extern "C" int amt_march_rows_for(long ntile_i, int nj, int cus, long max_rows)
+extern "C" int amt_march_rows_for(long ntile_i, int nj, int cus, long max_rows, int wbytes, int hl)
 {
-    return amt_march_rows(ntile_i, nj, cus, max_rows, nullptr, nullptr);
+    return amt_march_rows(ntile_i, nj, cus, max_rows, amt_march_rows_in_rounds(wbytes, hl), nullptr, nullptr);
 }
 
 // Shape preference.  Measured (profiles/r02_shapes.md): most waves to hide latency and fewest
@@ -1230,7 +1233,7 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
                 const int tc = (64 / q.hl) * q.vw;
                 double c = 0;
                 long rounds = 1;
-                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, amt_march_max_rows(p), &c, &rounds);
+                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, amt_march_max_rows(p), amt_march_rows_in_rounds((int)sizeof(T), q.hl), &c, &rounds);
                 return c * (q.hl == out.hl ? 1.0 : rounds == 1 ? 0.8 : 1.2);
             };
             if (out.hl < 4)
@@ -1297,7 +1300,7 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
     g.col_lo = amt_march_col_lo(p);
     g.ntile_i = (p.i1 - g.col_lo) / tc + 1;
     int jrows = env.jrows;
-    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), max_rows, nullptr, nullptr);
+    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), max_rows, amt_march_rows_in_rounds((int)sizeof(T), s.hl), nullptr, nullptr);
     if (jrows > nj) jrows = nj;
     if (jrows > max_rows) jrows = (int)max_rows;
     g.jrows = jrows;

@@ -97,7 +97,7 @@ SYMBOLS = {
     "amt_slab_barrier": (_I, [_P]),
     "amt_slab_max": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
     "amt_march_force_shape": (_I, [_I] * 7),
-    "amt_march_rows_for": (_I, [ctypes.c_long, _I, _I, ctypes.c_long]),
+    "amt_march_rows_for": (_I, [ctypes.c_long, _I, _I, ctypes.c_long, _I, _I]),
     "amt_march_set_xchunk": (_I, [_I]),
     "amt_march_last_kernel": (ctypes.c_char_p, []),
     "amt_march_selectable": (_I, [ctypes.c_char_p, _I]),
