@@ -200,9 +200,13 @@ def test_configs4_8192x80x8192_fp32_resident(pkg, oracle, torch_mod):
     jrows = int(m.group(1)) if m else 64
     rows = 64
     nblk = -(-(dims[2] - 2) // jrows)
-    seams = [2 + jrows * k for k in sorted({1, nblk // 4, nblk // 2, (3 * nblk) // 4, nblk - 2}) if 1 <= k < nblk]
-    assert len(seams) == 5, (label, seams)
+    seams = [2 + jrows * k for k in sorted({1, nblk // 4, nblk // 2, (3 * nblk) // 4, nblk - 2, nblk - 1}) if 1 <= k < nblk]
+    assert len(seams) >= 3, (label, seams)
     starts = [1, dims[2] - rows + 1] + [s - rows // 2 for s in seams]
+    k = 0
+    while len(starts) < 7:                                               # few, long blocks: add block interiors
+        starts.append(2 + jrows * k + jrows // 2)
+        k += 1
     checked = _check_rows_against_oracle(pkg, oracle, dev, b, cfg, dims, np.float32, seed, starts, rows,
                                          also_fp64=(starts[0], starts[3]))
     assert len(checked) >= 0.05 * dims[2], len(checked)

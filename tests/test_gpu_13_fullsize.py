@@ -103,6 +103,55 @@ def test_tenth_of_the_rows_of_configs2_against_the_oracle(pkg, oracle):
 
 
 @pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "page-locked"])
+
+@pytest.mark.parametrize("dtype,dims,rows_per_block", [(np.float32, (8192, 80, 2048), 1023), (np.float64, (4096, 80, 2048), 1023)])
+def test_blocks_whose_row_offsets_pass_2_gib(pkg, oracle, dtype, dims, rows_per_block):
+    """The march's per-lane byte offsets are unsigned 32-bit: a block may span up to 4 GiB (amt_march_max_rows).
+    80-level rows of 8192 fp32 / 4096 fp64 elements are 2.65 MB, so a 1023-row block ends 2.7 GB from its first row:
+    the last rows of both blocks of a tile (and the first ones) against the oracle, bit for bit.  The fp32 launch is the
+    launcher's own choice there (one round of 256 blocks); the fp64 one is forced (its shape stays at 64 rows)."""
+    import torch
+    S = pkg.synth
+    L = pkg.load_library()
+    b = S.domain_bounds(*dims, aligned=True)
+    wbytes = np.dtype(dtype).itemsize
+    need = 11.5 * b.idim * b.kdim * b.jdim * wbytes
+    if torch.cuda.mem_get_info(0)[0] < need:
+        pytest.skip(f"needs {need / 1e9:.0f} GB of free HBM")
+    cfg = pkg.GridConfig(specified=True)
+    seed = 9090
+    dev = S.make_patch(b, cfg, dtype=dtype, seed=seed, device="cuda:0")
+    forced = dtype == np.float64
+    if forced:
+        L.amt_march_force_shape(0, 0, 0, -1, 1, rows_per_block, 0)
+    try:
+        pkg.advance_mu_t(*dev.args())
+        torch.cuda.synchronize()
+        label = L.amt_march_last_kernel().decode()
+    finally:
+        if forced:
+            L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
+    m = re.search(r"jrows=(\d+)", label)
+    assert m and int(m.group(1)) == rows_per_block, label
+    row_bytes = b.idim * b.kdim * wbytes
+    assert (rows_per_block - 1) * row_bytes > 2**31, "the block must reach past 2 GiB"
+    rows = 24
+    first_row = 2                                               # specified: j_start = jds + 1
+    ends = [first_row + rows_per_block - 1, dims[2] - 1]        # last rows of the two blocks of a tile
+    starts = [first_row, first_row + rows_per_block] + [e - rows + 1 for e in ends] + [first_row + rows_per_block - 700]
+    threads = _granted_cores(rows)
+    for jlo in starts:
+        jhi = jlo + rows - 1
+        sb = b.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
+        want = S.make_patch(sb, cfg, dtype=dtype, seed=seed, global_dims=dims, device="cuda:0").to_host()
+        oracle.advance_mu_t_omp(*want.args(), nthreads=threads)
+        for n in S.OUTPUTS:
+            got = dev.arrays[n][jlo - b.jms: jhi + 1 - b.jms].cpu().numpy()
+            assert bits_equal(got, want.arrays[n][1:-1]), f"rows {jlo}..{jhi}: {n} differs from the oracle ({label})"
+    del dev
+    torch.cuda.empty_cache()
+
+
 def test_streamed_one_shot_on_a_many_chunk_domain(pkg, oracle, pinned):
     """Host arrays in, host arrays out (advance_mu_t_no_async.cu:245-306, 366-390 done with three
     streams): 2048 x 80 x 2048 fp32 goes up and comes down in ~45 chunks of 320 MB."""

@@ -1,7 +1,6 @@
 """The launcher's rows-per-workgroup rule (host arithmetic of the HIP library, no GPU): amt_march_rows_for
-against a brute-force restatement of the rule in DESIGN.md section 4.2 -- minimise rounds(r) * (r + 0.5), blocks of
-more than 128 rows (64 for the fp64 shapes with level groups) only when the whole launch is one round, never more rows than
-the 32-bit offsets span."""
+against a brute-force restatement of the rule in DESIGN.md section 4.2 -- minimise rounds(r) * (r + 0.5) over blocks of at most
+the rows the 32-bit offsets span, at most 64 rows for the fp64 shapes with level groups."""
 import math
 import random
 
@@ -9,13 +8,11 @@ import pytest
 
 
 def _rule(ntile, nj, cus, max_rows, wbytes=8, hl=1):
-    cap = 64 if (wbytes == 8 and hl >= 2) else 128
+    cap = 64 if (wbytes == 8 and hl >= 2) else 1 << 30
     best, pick = None, 1
-    for r in range(1, min(nj, max_rows) + 1):
+    for r in range(1, min(nj, max_rows, cap) + 1):
         blocks = ntile * math.ceil(nj / r)
         rounds = math.ceil(blocks / cus)
-        if rounds > 1 and r > cap:
-            continue
         cost = rounds * (r + 0.5)
         if best is None or cost < best - 1e-9 or (cost < best + 1e-9 and r > pick):
             best, pick = cost, r
@@ -31,10 +28,11 @@ def test_rows_of_the_baseline_configs(L):
     # (tiles, rows, CUs, rows the offsets span) -> rows per workgroup
     assert L.amt_march_rows_for(64, 4094, 256, 1070, 8, 1) == 1024      # configs[2] 4096x60x4096 fp64: 256 blocks, one round
     assert L.amt_march_rows_for(64, 510, 256, 1070, 8, 1) == 128        # configs[3] one j-slab of eight: one round
-    assert L.amt_march_rows_for(128, 8190, 256, 806, 4, 2) == 128       # configs[4] 8192x80x8192 fp32: 32 rounds
+    assert L.amt_march_rows_for(128, 8190, 256, 1615, 4, 2) == 1365     # configs[4] 8192x80x8192 fp32: 6 blocks per tile, 3 whole rounds
     assert L.amt_march_rows_for(8, 510, 256, 9999, 8, 1) == 16          # configs[1] 512x60x512: 256 blocks of 16 rows
     assert L.amt_march_rows_for(1, 64, 256, 9999, 8, 1) == 1            # one tile: a block per row
-    assert L.amt_march_rows_for(128, 2046, 256, 806, 8, 2) == 64        # 4096x80x2048 fp64, level groups: 64 rows in rounds
+    assert L.amt_march_rows_for(128, 2046, 256, 1615, 8, 2) == 64       # 4096x80x2048 fp64, level groups: 64 rows
+    assert L.amt_march_rows_for(128, 2046, 256, 1615, 4, 2) == 1023     # 8192x80x2048 fp32: one round
 
 
 def test_rows_rule_against_brute_force(L):
@@ -48,5 +46,5 @@ def test_rows_rule_against_brute_force(L):
         got = L.amt_march_rows_for(ntile, nj, cus, max_rows, wbytes, hl)
         assert got == _rule(ntile, nj, cus, max_rows, wbytes, hl), (ntile, nj, cus, max_rows, wbytes, hl)
         assert 1 <= got <= min(nj, max_rows)
-        if got > (64 if (wbytes == 8 and hl >= 2) else 128):
-            assert ntile * math.ceil(nj / got) <= cus
+        if wbytes == 8 and hl >= 2:
+            assert got <= 64

@@ -1097,10 +1097,13 @@ extern "C" int amt_march_set_xchunk(int xchunk)
 
 template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
 {
-    // the per-lane byte offsets of the march are 32-bit
+    // The per-lane byte offsets of the march are 32-bit and UNSIGNED: every access is (uniform 64-bit base) + (unsigned
+    // offset, zero-extended) -- `global_load v, v_off, s[base:base+1]` -- and the offsets only ever grow from the block's
+    // first row, so a block may span 4 GiB less the rows and levels read ahead (tests/test_gpu_13_fullsize.py runs blocks
+    // whose offsets pass 2 GiB against the oracle).
     const long row_bytes = p.jstride * (long)sizeof(T);
     if (row_bytes <= 0) return 1L << 30;             // no rows to step over (a shape query without a domain)
-    return ((1L << 31) - 40L * p.idim * (long)sizeof(T)) / row_bytes - 3;
+    return ((1L << 32) - 40L * p.idim * (long)sizeof(T)) / row_bytes - 3;
 }
 
 // Rows per workgroup.  A block costs its rows plus a prologue (4 extra array-rows of loads, about
@@ -1110,26 +1113,25 @@ template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
 // r = 32 would leave the last round 6 % full (1040 workgroups on 256 CUs) and cost 17 % more than
 // r = 11.  Small launches get short blocks, down to one row (more workgroups: 64x40x64 takes 12 us
 // with r = 1, 27 us with r = 4).
-// How long a block may be (profiles/r04_rows.md): in a launch of several rounds the CUs drift apart
-// by about 1 % (which XCD, which placement of the arrays) and the launch ends with its slowest CU, a
-// tail that grows with the block: up to 128 rows the saved prologues win (-0.3 .. -0.6 % against 64
-// rows), 256 rows and more lose where the launch still has rounds (4096x80x2048 fp64 +2 %).  A launch
-// that is ONE round -- as many blocks as CUs, each as long as it takes -- has no round to wait for and
-// 1/16 of the prologues: 4096x60x4096 fp64 1024 rows -1.0 .. -2.3 %, 4096x60x512 128 rows -2.8 .. -3.5 %.
-// The fp64 shapes with level groups (32-column tiles) stay at 64 rows in rounds: with 128 the launch takes the same
-// time (4096x80x2048: +0.5 / +0.2 / -0.1 % on three placements) and reads 1.8 % more (46.19 against 45.37 GB: neighbouring
-// tiles drift apart and lose each other's halo lines in L2).
-// `max_rows`: what the 32-bit row offsets of a block can span.
-static int amt_march_rows_in_rounds(int wbytes, int hl) { return (wbytes == 8 && hl >= 2) ? 64 : 128; }
-static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, int rows_in_rounds, double *cost_out, long *rounds_out)
+// How long a block may be (profiles/r04_rows.md): r03 capped it at 64 rows.  Recorded per workgroup (profiles/spans.py), a
+// 16-round launch pays 16 prologues per CU and ends 110-200 us after its median CU (a block is about 1 % slower on some
+// XCDs than on others, and every XCD gets one eighth of the blocks); dispatch gaps are 1 us.  Fewer, longer blocks save the
+// prologues the model counts (4096x60x8192 fp64 512 rows -0.3 %, 8192x80x8192 fp32 683 rows = 6 whole rounds -0.7 %
+// against 128 rows), and a launch that is ONE round -- as many blocks as CUs, each as long as it takes -- saves five times
+// that: 4096x60x4096 fp64 1024 rows -1.3 .. -1.6 %, 4096x60x512 128 rows -2.0 .. -3.0 %, 8192x80x2048 fp32 -2.8 .. -3.9 %.
+// So: no cap beyond what the 32-bit row offsets span (`max_rows`) -- except for the fp64 shapes with level groups
+// (32-column tiles), which stay at 64 rows: at 128 they take the same time and read 1.8 % more (neighbouring tiles drift
+// apart over a long block and lose each other's halo lines in L2: 46.19 against 45.37 GB for 4096x80x2048), at 256 and
+// more they are 1 .. 2 % slower, in rounds or as one round.
+static int amt_march_rows_cap(int wbytes, int hl) { return (wbytes == 8 && hl >= 2) ? 64 : 1 << 30; }
+static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, int cap, double *cost_out, long *rounds_out)
 {
     double best = 1e300;
     int jrows = 1;
     long brounds = 1;
-    for (int r = 1; r <= nj && r <= max_rows; ++r) {
+    for (int r = 1; r <= nj && r <= max_rows && r <= cap; ++r) {
         const long blocks = ntile_i * ((nj + r - 1) / r);
         const long rounds = (blocks + cus - 1) / cus;
-        if (rounds > 1 && r > rows_in_rounds) continue;
         const double cost = (double)rounds * (r + 0.5);
         if (cost < best - 1e-9 || (cost < best + 1e-9 && r > jrows)) { best = cost; jrows = r; brounds = rounds; }
     }
@@ -1141,7 +1143,7 @@ static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, int rows
 // the row-count rule alone, for the host-logic tests (tests/test_march_rows.py)
 extern "C" int amt_march_rows_for(long ntile_i, int nj, int cus, long max_rows, int wbytes, int hl)
 {
-    return amt_march_rows(ntile_i, nj, cus, max_rows, amt_march_rows_in_rounds(wbytes, hl), nullptr, nullptr);
+    return amt_march_rows(ntile_i, nj, cus, max_rows, amt_march_rows_cap(wbytes, hl), nullptr, nullptr);
 }
 
 // Shape preference.  Measured (profiles/r02_shapes.md): most waves to hide latency and fewest
@@ -1233,7 +1235,7 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
                 const int tc = (64 / q.hl) * q.vw;
                 double c = 0;
                 long rounds = 1;
-                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, amt_march_max_rows(p), amt_march_rows_in_rounds((int)sizeof(T), q.hl), &c, &rounds);
+                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, amt_march_max_rows(p), amt_march_rows_cap((int)sizeof(T), q.hl), &c, &rounds);
                 return c * (q.hl == out.hl ? 1.0 : rounds == 1 ? 0.8 : 1.2);
             };
             if (out.hl < 4)
@@ -1300,7 +1302,7 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
     g.col_lo = amt_march_col_lo(p);
     g.ntile_i = (p.i1 - g.col_lo) / tc + 1;
     int jrows = env.jrows;
-    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), max_rows, amt_march_rows_in_rounds((int)sizeof(T), s.hl), nullptr, nullptr);
+    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), max_rows, amt_march_rows_cap((int)sizeof(T), s.hl), nullptr, nullptr);
     if (jrows > nj) jrows = nj;
     if (jrows > max_rows) jrows = (int)max_rows;
     g.jrows = jrows;
