@@ -102,7 +102,6 @@ def test_tenth_of_the_rows_of_configs2_against_the_oracle(pkg, oracle):
     assert time.time() - t0 < 90
 
 
-@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "page-locked"])
 
 @pytest.mark.parametrize("dtype,dims,rows_per_block", [(np.float32, (8192, 80, 2048), 1023), (np.float64, (4096, 80, 2048), 1023)])
 def test_blocks_whose_row_offsets_pass_2_gib(pkg, oracle, dtype, dims, rows_per_block):
@@ -152,6 +151,7 @@ def test_blocks_whose_row_offsets_pass_2_gib(pkg, oracle, dtype, dims, rows_per_
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "page-locked"])
 def test_streamed_one_shot_on_a_many_chunk_domain(pkg, oracle, pinned):
     """Host arrays in, host arrays out (advance_mu_t_no_async.cu:245-306, 366-390 done with three
     streams): 2048 x 80 x 2048 fp32 goes up and comes down in ~45 chunks of 320 MB."""
