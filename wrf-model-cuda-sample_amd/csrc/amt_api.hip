@@ -182,10 +182,26 @@ int amt_device_call(void *hip_stream, int variant, const AmtArgs<T> &a)
     return amt_launch<T>(static_cast<hipStream_t>(hip_stream), variant, p);
 }
 
+// The same launch when another stream's kernels are to run beside it (amt_slab.hip: the interior rows of a j-slab
+// while the halo exchange and the edge rows go through the communication stream).
+template <typename T>
+int amt_device_call_shared(void *hip_stream, int variant, const AmtArgs<T> &a)
+{
+    AmtParams<T> p;
+    AmtWindow w;
+    bool empty = false;
+    int rc = amt_build_params(a, p, w, &empty);
+    if (rc != AMT_OK || empty) return rc;
+    p.edges = 2;
+    return amt_launch<T>(static_cast<hipStream_t>(hip_stream), variant, p);
+}
+
 template int amt_build_params<float>(const AmtArgs<float> &, AmtParams<float> &, AmtWindow &, bool *);
 template int amt_build_params<double>(const AmtArgs<double> &, AmtParams<double> &, AmtWindow &, bool *);
 template int amt_device_call<float>(void *, int, const AmtArgs<float> &);
 template int amt_device_call<double>(void *, int, const AmtArgs<double> &);
+template int amt_device_call_shared<float>(void *, int, const AmtArgs<float> &);
+template int amt_device_call_shared<double>(void *, int, const AmtArgs<double> &);
 template int amt_device_call_edges<float>(void *, int, const AmtArgs<float> &);
 template int amt_device_call_edges<double>(void *, int, const AmtArgs<double> &);
 

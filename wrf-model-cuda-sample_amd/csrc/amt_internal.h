@@ -53,6 +53,10 @@ extern template int amt_build_params<float>(const AmtArgs<float> &, AmtParams<fl
 extern template int amt_build_params<double>(const AmtArgs<double> &, AmtParams<double> &, AmtWindow &, bool *);
 extern template int amt_device_call<float>(void *, int, const AmtArgs<float> &);
 extern template int amt_device_call<double>(void *, int, const AmtArgs<double> &);
+// the whole window, launched beside another stream's kernels (planned in at least two rounds of workgroups)
+template <typename T> int amt_device_call_shared(void *hip_stream, int variant, const AmtArgs<T> &a);
+extern template int amt_device_call_shared<float>(void *, int, const AmtArgs<float> &);
+extern template int amt_device_call_shared<double>(void *, int, const AmtArgs<double> &);
 extern template int amt_device_call_edges<float>(void *, int, const AmtArgs<float> &);
 extern template int amt_device_call_edges<double>(void *, int, const AmtArgs<double> &);
 

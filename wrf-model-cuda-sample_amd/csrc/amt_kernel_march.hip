@@ -1124,7 +1124,7 @@ template <typename T> static long amt_march_max_rows(const AmtParams<T> &p)
 // apart over a long block and lose each other's halo lines in L2: 46.19 against 45.37 GB for 4096x80x2048), at 256 and
 // more they are 1 .. 2 % slower, in rounds or as one round.
 static int amt_march_rows_cap(int wbytes, int hl) { return (wbytes == 8 && hl >= 2) ? 64 : 1 << 30; }
-static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, int cap, double *cost_out, long *rounds_out)
+static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, int cap, int min_rounds, double *cost_out, long *rounds_out)
 {
     double best = 1e300;
     int jrows = 1;
@@ -1132,6 +1132,7 @@ static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, int cap,
     for (int r = 1; r <= nj && r <= max_rows && r <= cap; ++r) {
         const long blocks = ntile_i * ((nj + r - 1) / r);
         const long rounds = (blocks + cus - 1) / cus;
+        if (rounds < min_rounds && r > 1) continue;      // a launch beside another stream's kernels (AmtParams::edges == 2)
         const double cost = (double)rounds * (r + 0.5);
         if (cost < best - 1e-9 || (cost < best + 1e-9 && r > jrows)) { best = cost; jrows = r; brounds = rounds; }
     }
@@ -1143,7 +1144,7 @@ static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, int cap,
 // the row-count rule alone, for the host-logic tests (tests/test_march_rows.py)
 extern "C" int amt_march_rows_for(long ntile_i, int nj, int cus, long max_rows, int wbytes, int hl)
 {
-    return amt_march_rows(ntile_i, nj, cus, max_rows, amt_march_rows_cap(wbytes, hl), nullptr, nullptr);
+    return amt_march_rows(ntile_i, nj, cus, max_rows, amt_march_rows_cap(wbytes, hl), 1, nullptr, nullptr);
 }
 
 // Shape preference.  Measured (profiles/r02_shapes.md): most waves to hide latency and fewest
@@ -1230,12 +1231,12 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
         // (profiles/r02_small_domains.md: 64x40x64 11 -> 9 us, 128x60x128 fp64 30 -> 23 us), while in
         // a launch of several rounds it moves fewer bytes per second (512x60x512: 1.17x the time).
         {
-            const int nj = p.edges ? 2 : p.j1 - p.j0 + 1, cus = amt_march_cus(-1);
+            const int nj = p.edges == 1 ? 2 : p.j1 - p.j0 + 1, cus = amt_march_cus(-1);
             auto model = [&](const AmtMarchShape &q) {
                 const int tc = (64 / q.hl) * q.vw;
                 double c = 0;
                 long rounds = 1;
-                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, amt_march_max_rows(p), amt_march_rows_cap((int)sizeof(T), q.hl), &c, &rounds);
+                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, amt_march_max_rows(p), amt_march_rows_cap((int)sizeof(T), q.hl), p.edges == 2 ? 2 : 1, &c, &rounds);
                 return c * (q.hl == out.hl ? 1.0 : rounds == 1 ? 0.8 : 1.2);
             };
             if (out.hl < 4)
@@ -1302,13 +1303,13 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
     g.col_lo = amt_march_col_lo(p);
     g.ntile_i = (p.i1 - g.col_lo) / tc + 1;
     int jrows = env.jrows;
-    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), max_rows, amt_march_rows_cap((int)sizeof(T), s.hl), nullptr, nullptr);
+    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), max_rows, amt_march_rows_cap((int)sizeof(T), s.hl), p.edges == 2 ? 2 : 1, nullptr, nullptr);
     if (jrows > nj) jrows = nj;
     if (jrows > max_rows) jrows = (int)max_rows;
     g.jrows = jrows;
     g.jstep = jrows;
     g.njblk = (nj + jrows - 1) / jrows;
-    if (p.edges) {                                   // rows j0 and j1 only: two one-row blocks
+    if (p.edges == 1) {                              // rows j0 and j1 only: two one-row blocks
         g.jrows = 1;
         g.jstep = nj - 1;
         g.njblk = 2;
@@ -1374,7 +1375,7 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
     if (!pl) return hipErrorNotSupported;
     pl->entry->launch[pl->full](stream, p, pl->grid, pl->nw, pl->lds);
     // the kernel the calling thread LAUNCHED last (a slab's one-row edge launch does not rename its interior kernel)
-    if (!p.edges && strcmp(g_march_last, pl->label) != 0) snprintf(g_march_last, sizeof g_march_last, "%s", pl->label);
+    if (p.edges != 1 && strcmp(g_march_last, pl->label) != 0) snprintf(g_march_last, sizeof g_march_last, "%s", pl->label);
     return hipGetLastError();
 }
 

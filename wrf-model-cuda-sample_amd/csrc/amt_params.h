@@ -22,6 +22,9 @@ struct AmtParams {
     int k1;                // memory index of Fortran level k = 1   (1 - kms)
     int nk;                // k_end = kte - 1 : levels 1..nk are updated
     int edges;             // 1: only rows j0 and j1 of the window (a j-slab's two boundary rows in ONE launch)
+                           // 2: the whole window, launched BESIDE another stream's kernels (a j-slab's interior rows while its
+                           //    halo exchange runs): planned in at least two rounds of workgroups, so that the other stream's
+                           //    kernels get compute units at a round boundary instead of behind the whole launch
 };
 
 // Compute window, module_small_step_em.f90:91-106.

@@ -374,13 +374,16 @@ __global__ void amt_slab_delay_kernel(unsigned long long ticks)
 }
 
 template <typename T>
-int amt_slab_tile(amt_slab *s, hipStream_t stream, int jts, int jte)
+int amt_slab_tile(amt_slab *s, hipStream_t stream, int jts, int jte, bool beside_the_exchange = false)
 {
     if (jte < jts) return AMT_OK;
     AmtArgs<T> a;
     amt_domain_args<T>(s->dom, a);
     a.jts = jts; a.jte = jte;
-    return amt_device_call<T>(stream, s->dom->variant, a);
+    // A launch that is ONE round of workgroups (the launcher's choice for a slab on its own) holds every compute unit
+    // until it ends: the exchange's kernels and the edge rows would start behind it and the wire time would show in full
+    // (profiles/r04_raw/slab_order/).  Beside the exchange the interior is planned in at least two rounds.
+    return beside_the_exchange ? amt_device_call_shared<T>(stream, s->dom->variant, a) : amt_device_call<T>(stream, s->dom->variant, a);
 }
 
 template <typename T>
@@ -417,7 +420,7 @@ int amt_slab_step_t(amt_slab *s, int n_sweeps)
         if (s->overlap) {
             AMT_HIP(hipEventRecord(s->inputs_final, d->stream));          // this sub-step's inputs are final
             AMT_HIP(hipStreamWaitEvent(s->comm_stream, s->inputs_final, 0));
-            rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi);              // interior overlaps the exchange
+            rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi, true);        // interior overlaps the exchange
             if (rc) { join(); return rc; }
         }
         if (s->skew_us > 0)
