@@ -69,6 +69,11 @@ enum amt_variant {
     AMT_VARIANT_COLUMN = 1,    /* one lane per (i,j) column, k-column staged in LDS */
     AMT_VARIANT_MARCH = 2      /* (i,k)-cell lanes marching in j, k-chains through LDS */
 };
+/* OR-ed into the `variant` argument of amt_advance_mu_t_device_*: kernels of ANOTHER stream are meant to run beside this
+ * launch (a j-slab's interior rows while its halo exchange and edge rows go through a communication stream).  On its own a
+ * launch may be planned as ONE round of workgroups that holds every compute unit until it ends; with this flag it is
+ * planned in at least two rounds, so that the other stream's kernels get compute units at a round boundary.  Same bits. */
+#define AMT_LAUNCH_BESIDE_OTHERS 0x100
 
 const char *amt_version(void);
 const char *amt_status_string(int status);

@@ -381,6 +381,37 @@ def test_resident_domain_handle(pkg, oracle, torch_mod):
         lib.check(L.amt_domain_destroy(h))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_launch_beside_others_plans_two_rounds_and_the_same_bits(pkg, oracle, torch_mod, dtype):
+    """AMT_LAUNCH_BESIDE_OTHERS (what the slab stepper's interior launch carries while the halo exchange runs): a launch that
+    would be ONE round of workgroups on its own is planned in at least two, so that another stream's kernels get compute units
+    at a round boundary; the results are the same bits."""
+    import re
+    torch = torch_mod
+    S = pkg.synth
+    L = pkg.load_library()
+    cols = 64 if dtype == np.float64 else 128                       # columns per tile of the shapes chosen here
+    b = S.domain_bounds(16 * cols, 20, 512)                         # 16 tiles x 512 rows: 256 blocks of 32 rows = one round
+    host = S.make_patch(b, pkg.GridConfig(), dtype=dtype, seed=31)
+    want = host.copy()
+    oracle.advance_mu_t(*want.args())
+    labels = {}
+    for flag in (0, pkg.LAUNCH_BESIDE_OTHERS):
+        dev = host.to_device("cuda:0")
+        pkg.advance_mu_t(*dev.args(), variant=pkg.VARIANT_MARCH | flag)
+        torch.cuda.synchronize()
+        labels[flag] = L.amt_march_last_kernel().decode()
+        assert_patch_equal(pkg, dev.to_host(), want, f"variant flag {flag:#x} ({labels[flag]})")
+    rows = {f: int(re.search(r"jrows=(\d+)", lab).group(1)) for f, lab in labels.items()}
+    ntile = -(-(b.ite - b.its + 1) // cols)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    nj = b.jte - b.jts + 1
+    blocks = {f: ntile * -(-nj // r) for f, r in rows.items()}
+    if blocks[0] <= cus:                                            # the plain launch is one round on this device
+        assert blocks[pkg.LAUNCH_BESIDE_OTHERS] > cus, (labels, blocks)
+        assert rows[pkg.LAUNCH_BESIDE_OTHERS] < rows[0], labels
+
+
 def test_placement_tuning_keeps_the_contents_and_a_working_handle(pkg, oracle, torch_mod):
     """amt_domain_tune_placement: the handle's arrays are re-allocated a few times and the fastest set kept -- every array
     must hold afterwards what it held before (inputs AND the in/out state the timed sweeps advanced), and the next

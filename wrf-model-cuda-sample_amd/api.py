@@ -21,6 +21,7 @@ from . import lib as _lib
 from .config import flags_as_ints
 
 VARIANT_AUTO, VARIANT_COLUMN, VARIANT_MARCH = 0, 1, 2
+LAUNCH_BESIDE_OTHERS = 0x100      # OR into `variant`: another stream's kernels run beside this launch (include/amt_advance_mu_t.h)
 
 
 def compute_window(config_flags, ids, ide, jds, jde, its, ite, jts, jte, kts, kte):

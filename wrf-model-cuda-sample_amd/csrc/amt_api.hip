@@ -208,11 +208,13 @@ template int amt_device_call_edges<double>(void *, int, const AmtArgs<double> &)
 extern "C" int amt_advance_mu_t_device_f32(void *hip_stream, int variant, AMT_SIG(float))
 {
     AMT_PACK_ARGS(float)
+    if (variant & AMT_LAUNCH_BESIDE_OTHERS) return amt_device_call_shared<float>(hip_stream, variant & ~AMT_LAUNCH_BESIDE_OTHERS, a);
     return amt_device_call<float>(hip_stream, variant, a);
 }
 extern "C" int amt_advance_mu_t_device_f64(void *hip_stream, int variant, AMT_SIG(double))
 {
     AMT_PACK_ARGS(double)
+    if (variant & AMT_LAUNCH_BESIDE_OTHERS) return amt_device_call_shared<double>(hip_stream, variant & ~AMT_LAUNCH_BESIDE_OTHERS, a);
     return amt_device_call<double>(hip_stream, variant, a);
 }
 

@@ -125,19 +125,20 @@ class SlabStepper:
         return n
 
     # -- one sweep ---------------------------------------------------------------------
-    def _tile(self, jts: int, jte: int, stream):
+    def _tile(self, jts: int, jte: int, stream, beside: bool = False):
         if jte < jts:
             return
         if self.on_gpu:
-            key = (jts, jte, id(stream))
+            variant = self.variant | (0x100 if beside else 0)        # LAUNCH_BESIDE_OTHERS: leave round boundaries to the exchange
+            key = (jts, jte, id(stream), beside)
             call = self._bound.get(key)
             if call is None:
                 args = self.patch.with_bounds(jts=jts, jte=jte).args()
                 binder = getattr(self.compute, "bind", None)
                 if binder is None:                   # a plain callable: marshal on every call
-                    self.compute(*args, stream=stream, variant=self.variant)
+                    self.compute(*args, stream=stream, variant=variant)
                     return
-                call = self._bound[key] = binder(*args, stream=stream, variant=self.variant)
+                call = self._bound[key] = binder(*args, stream=stream, variant=variant)
             call()
         else:
             self.compute(*self.patch.with_bounds(jts=jts, jte=jte).args())
@@ -157,7 +158,7 @@ class SlabStepper:
             # inputs).  main stream: the interior.  The small edge launches (one row each) then fill
             # the CUs that the interior's last, partly filled round of workgroups leaves idle.
             self.comm_stream.wait_stream(self.main_stream)      # inputs of this sub-step are final
-            self._tile(in_lo, in_hi, self.main_stream)          # interior overlaps the exchange
+            self._tile(in_lo, in_hi, self.main_stream, beside=True)   # interior overlaps the exchange
             with torch.cuda.stream(self.comm_stream):
                 self.exchange_halos()                           # RCCL send/recv on the comm stream
                 self._edges(jlo, jhi, self.comm_stream)
