@@ -64,3 +64,31 @@ def test_tall_domains_match_oracle(pkg, oracle):
         del dev
     assert seen_long >= 3, "the seeded cases should include blocks of more than 64 rows"
     assert seen_beside >= 5
+
+
+@pytest.mark.parametrize("xchunk", [1, 5, 32])
+def test_workgroup_to_block_mapping_knob_keeps_the_bits(pkg, oracle, xchunk):
+    """amt_march_set_xchunk only changes WHICH workgroup marches which block: a launch of several rounds with a ragged
+    last round (17 tiles x 39 blocks = 663 workgroups) gives the same bits under every mapping."""
+    import torch
+    torch.cuda.set_device(0)
+    S = pkg.synth
+    L = pkg.load_library()
+    b = S.domain_bounds(1060, 20, 310)
+    cfg = pkg.GridConfig(specified=True)
+    host = S.make_patch(b, cfg, dtype=np.float64, seed=77)
+    want = host.copy()
+    oracle.advance_mu_t_omp(*want.args(), nthreads=8)
+    L.amt_march_force_shape(0, 0, 0, -1, 1, 8, 0)                   # 8-row blocks: several rounds on any device
+    L.amt_march_set_xchunk(xchunk)
+    try:
+        dev = host.to_device("cuda:0")
+        pkg.advance_mu_t(*dev.args(), variant=pkg.VARIANT_MARCH)
+        torch.cuda.synchronize()
+        label = L.amt_march_last_kernel().decode()
+    finally:
+        L.amt_march_set_xchunk(0)
+        L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
+    got = dev.to_host()
+    for n in S.OUTPUTS:
+        assert bits_equal(got.arrays[n], want.arrays[n]), f"xchunk {xchunk}: {n} ({label})"
