@@ -408,7 +408,8 @@ def cpu_baseline(dims, dtype_name, seed, rows, seconds):
         name = {"c": "port_c", "fortran": "fortran", "reference_nodump": "reference_fortran_compute_only",
                 "reference": "reference_fortran_incl_dumps"}[impl]
         rec = {"impl": name, "size": rec["size"] + (f" ({what})" if what else ""), "threads": rec["threads"],
-               "Mcells_s": rec["Mcells_s"], "ms_per_sweep": rec["ms_per_sweep"], "sweeps": rec["sweeps"], "fill_s": rec["fill_s"]}
+               "Mcells_s": rec["Mcells_s"], "ms_per_sweep": rec["ms_per_sweep"], "sweeps": rec["sweeps"], "fill_s": rec["fill_s"],
+               "Mcells_s_fastest_sweep": rec.get("Mcells_s_fastest_sweep")}
         matrix.append(rec)
         return rec
 
@@ -447,6 +448,7 @@ def cpu_baseline(dims, dtype_name, seed, rows, seconds):
            "sample": f"{ni}x{nk}x{slab_rows} j-slab (rows {gj0 + 1}..{gj0 + slab_rows}) of the same synthetic domain, median sweep, "
                      f"{slab['threads'] if slab else cores} OpenMP j-tiles, pages first touched by their tile's thread",
            "ms_per_sweep_sample": slab["ms_per_sweep"] if slab else None,
+           "fastest_sweep_Mcells_s": slab.get("Mcells_s_fastest_sweep") if slab else None,   # the host is shared: its best sweep beside the median
            "one_thread_Mcells_s": one["Mcells_s"] if one else None,
            "host": quota_note + (f", MemAvailable {avail / 2**30:.0f} GiB" if avail else ""),
            "leg_seconds": round(time.perf_counter() - t_leg, 1),
