@@ -2,7 +2,11 @@
 workgroups wherever the launch can be one, profiles/r04_rows.md), the last block of a tile is ragged, and with
 AMT_LAUNCH_BESIDE_OTHERS the same launch is planned in at least two rounds.  Whole outputs against the oracle, bit for
 bit, on seeded random shapes."""
+import json
+import os
 import re
+import time
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -11,8 +15,8 @@ from conftest import bits_equal
 
 pytestmark = pytest.mark.gpu
 
-SEED = 20261003
-N_CASES = 14
+SEED = int(os.environ.get("AMT_TALL_SEED", "20261003"))
+N_CASES = int(os.environ.get("AMT_TALL_CASES", "14"))          # a longer campaign: AMT_TALL_CASES=300
 
 
 # few tiles x many rows: one round of blocks well beyond 64 rows (the last one of a tile ragged)
@@ -26,9 +30,14 @@ def _case(rng, pkg, case):
         ni, nk, nj, dtype = LONG[case]
     else:
         dtype = np.float64 if rng.random() < 0.5 else np.float32
-        ni = int(rng.choice([64, 100, 192, 257, 512, 700, 1024, 1500, 2048]))
-        nk = int(rng.choice([4, 8, 13, 20, 30, 40]))
-        nj = int(rng.choice([130, 200, 255, 510, 777, 1000, 1500, 2047, 3000]))
+        if rng.random() < 0.6:                      # many columns in all: one round of blocks of more than 64 rows
+            ni = int(rng.choice([512, 700, 1024, 1500, 2048, 3000, 4096]))
+            nk = int(rng.choice([20, 24, 30, 31]))
+            nj = int(rng.choice([510, 777, 1000, 1500, 2047, 3000])) + int(rng.integers(0, 3))
+        else:
+            ni = int(rng.choice([64, 100, 192, 257, 512, 700, 1024, 1500, 2048]))
+            nk = int(rng.choice([4, 8, 13, 20, 30, 40]))
+            nj = int(rng.choice([130, 200, 255, 510, 777, 1000, 1500, 2047, 3000]))
         while ni * nk * nj > 50_000_000:
             nj = max(130, nj // 2)
     aligned = bool(rng.integers(0, 2))
@@ -44,6 +53,7 @@ def test_tall_domains_match_oracle(pkg, oracle):
     S = pkg.synth
     L = pkg.load_library()
     seen_long, seen_beside = 0, 0
+    t_start = time.time()
     for case in range(N_CASES):
         b, cfg, dtype, dims = _case(rng, pkg, case)
         beside = case % 2 == 1
@@ -64,6 +74,13 @@ def test_tall_domains_match_oracle(pkg, oracle):
         del dev
     assert seen_long >= 3, "the seeded cases should include blocks of more than 64 rows"
     assert seen_beside >= 5
+    out = Path(__file__).resolve().parent.parent / "gpurun_out"
+    if N_CASES > 14 and out.is_dir():
+        (out / f"tall_campaign_{N_CASES}.json").write_text(json.dumps({
+            "seed": SEED, "cases": N_CASES, "blocks_of_more_than_64_rows": int(seen_long), "launched_beside_others": int(seen_beside),
+            "failures": 0, "wall_s": round(time.time() - t_start, 1),
+            "what": "tests/test_gpu_14_tall.py: few tiles x many rows (to 4096 columns, 3000 rows, 40 levels), random flags and "
+                    "precisions, every other case with AMT_LAUNCH_BESIDE_OTHERS; whole outputs bit-exact against the oracle"}, indent=1) + "\n")
 
 
 @pytest.mark.parametrize("xchunk", [1, 5, 32])
