@@ -151,6 +151,51 @@ def test_blocks_whose_row_offsets_pass_2_gib(pkg, oracle, dtype, dims, rows_per_
     torch.cuda.empty_cache()
 
 
+def test_a_block_at_the_offset_limit(pkg, oracle):
+    """The longest block the launcher allows: forced to more rows than the 32-bit offsets span, the block is clipped to
+    amt_march_max_rows -- (4 GiB - 40 level rows) / row bytes - 3 -- and its last rows sit within a few rows of the 4 GiB
+    mark.  512 x 60 columns-by-levels rows of 253 760 bytes: 16 900-odd rows per block; the last rows of that block, the
+    first ones of the next and both domain edges against the oracle."""
+    import torch
+    S = pkg.synth
+    L = pkg.load_library()
+    dims = (512, 60, 17400)
+    b = S.domain_bounds(*dims, aligned=True)
+    need = 11.5 * b.idim * b.kdim * b.jdim * 8
+    if torch.cuda.mem_get_info(0)[0] < need:
+        pytest.skip(f"needs {need / 1e9:.0f} GB of free HBM")
+    cfg = pkg.GridConfig(specified=True)
+    seed = 1717
+    dev = S.make_patch(b, cfg, dtype=np.float64, seed=seed, device="cuda:0")
+    L.amt_march_force_shape(0, 0, 0, -1, 1, 1 << 30, 0)
+    try:
+        pkg.advance_mu_t(*dev.args())
+        torch.cuda.synchronize()
+        label = L.amt_march_last_kernel().decode()
+    finally:
+        L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
+    jrows = int(re.search(r"jrows=(\d+)", label).group(1))
+    row_bytes = b.idim * b.kdim * 8
+    limit = (2**32 - 40 * b.idim * 8) // row_bytes - 3
+    assert jrows == limit, (label, limit)
+    assert (jrows + 2) * row_bytes <= 2**32 < (jrows + 6) * row_bytes + 40 * b.idim * 8, "the block should end at the mark"
+    rows = 24
+    first_row = 2                                               # specified: j_start = jds + 1
+    seam = first_row + jrows                                     # first row of the second block
+    starts = [1, dims[2] - rows + 1, seam - rows, seam, seam - 3000]
+    threads = _granted_cores(rows)
+    for jlo in starts:
+        jhi = jlo + rows - 1
+        sb = b.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
+        want = S.make_patch(sb, cfg, dtype=np.float64, seed=seed, global_dims=dims, device="cuda:0").to_host()
+        oracle.advance_mu_t_omp(*want.args(), nthreads=threads)
+        for n in S.OUTPUTS:
+            got = dev.arrays[n][jlo - b.jms: jhi + 1 - b.jms].cpu().numpy()
+            assert bits_equal(got, want.arrays[n][1:-1]), f"rows {jlo}..{jhi}: {n} differs from the oracle ({label})"
+    del dev
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "page-locked"])
 def test_streamed_one_shot_on_a_many_chunk_domain(pkg, oracle, pinned):
     """Host arrays in, host arrays out (advance_mu_t_no_async.cu:245-306, 366-390 done with three
