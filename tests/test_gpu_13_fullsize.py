@@ -151,34 +151,40 @@ def test_blocks_whose_row_offsets_pass_2_gib(pkg, oracle, dtype, dims, rows_per_
     torch.cuda.empty_cache()
 
 
-def test_a_block_at_the_offset_limit(pkg, oracle):
+@pytest.mark.parametrize("dtype,ni,nk,dma", [(np.float64, 512, 60, 1), (np.float32, 1024, 80, 1), (np.float64, 512, 60, 0)],
+                         ids=["f64-60", "f32-80-level-groups", "f64-60-register-flavour"])
+def test_a_block_at_the_offset_limit(pkg, oracle, dtype, ni, nk, dma):
     """The longest block the launcher allows: forced to more rows than the 32-bit offsets span, the block is clipped to
     amt_march_max_rows -- (4 GiB - 40 level rows) / row bytes - 3 -- and its last rows sit within a few rows of the 4 GiB
-    mark.  512 x 60 columns-by-levels rows of 253 760 bytes: 16 900-odd rows per block; the last rows of that block, the
-    first ones of the next and both domain edges against the oracle."""
+    mark (fp64: 512 x 60 columns-by-levels rows of 253 760 bytes, 16 900-odd rows per block; fp32: the level-group shape
+    of 80 levels): the last rows of that block, the first ones of the next and both domain edges against the oracle."""
     import torch
     S = pkg.synth
     L = pkg.load_library()
-    dims = (512, 60, 17400)
+    wbytes = np.dtype(dtype).itemsize
+    b0 = S.domain_bounds(ni, nk, 8, aligned=True)
+    row_bytes = b0.idim * b0.kdim * wbytes
+    limit = (2**32 - 40 * b0.idim * wbytes) // row_bytes - 3
+    dims = (ni, nk, limit + 400)
     b = S.domain_bounds(*dims, aligned=True)
-    need = 11.5 * b.idim * b.kdim * b.jdim * 8
+    assert (b.idim, b.kdim) == (b0.idim, b0.kdim)
+    need = 11.5 * b.idim * b.kdim * b.jdim * wbytes
     if torch.cuda.mem_get_info(0)[0] < need:
         pytest.skip(f"needs {need / 1e9:.0f} GB of free HBM")
     cfg = pkg.GridConfig(specified=True)
     seed = 1717
-    dev = S.make_patch(b, cfg, dtype=np.float64, seed=seed, device="cuda:0")
-    L.amt_march_force_shape(0, 0, 0, -1, 1, 1 << 30, 0)
+    dev = S.make_patch(b, cfg, dtype=dtype, seed=seed, device="cuda:0")
+    L.amt_march_force_shape(0, 0, 0, -1, dma, 1 << 30, 0)
     try:
         pkg.advance_mu_t(*dev.args())
         torch.cuda.synchronize()
         label = L.amt_march_last_kernel().decode()
     finally:
         L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
+    assert ("true, 16>" in label or "true, 12>" in label) == bool(dma), label
     jrows = int(re.search(r"jrows=(\d+)", label).group(1))
-    row_bytes = b.idim * b.kdim * 8
-    limit = (2**32 - 40 * b.idim * 8) // row_bytes - 3
     assert jrows == limit, (label, limit)
-    assert (jrows + 2) * row_bytes <= 2**32 < (jrows + 6) * row_bytes + 40 * b.idim * 8, "the block should end at the mark"
+    assert (jrows + 2) * row_bytes <= 2**32 < (jrows + 6) * row_bytes + 40 * b.idim * wbytes, "the block should end at the mark"
     rows = 24
     first_row = 2                                               # specified: j_start = jds + 1
     seam = first_row + jrows                                     # first row of the second block
@@ -187,7 +193,7 @@ def test_a_block_at_the_offset_limit(pkg, oracle):
     for jlo in starts:
         jhi = jlo + rows - 1
         sb = b.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
-        want = S.make_patch(sb, cfg, dtype=np.float64, seed=seed, global_dims=dims, device="cuda:0").to_host()
+        want = S.make_patch(sb, cfg, dtype=dtype, seed=seed, global_dims=dims, device="cuda:0").to_host()
         oracle.advance_mu_t_omp(*want.args(), nthreads=threads)
         for n in S.OUTPUTS:
             got = dev.arrays[n][jlo - b.jms: jhi + 1 - b.jms].cpu().numpy()
