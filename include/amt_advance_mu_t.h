@@ -384,7 +384,7 @@ int amt_march_selectable(char *buf, int cap);
 /* Rows per workgroup the launcher gives `ntile_i` column tiles of `nj` rows on `cus` compute units when a block's
  * unsigned 32-bit row offsets span at most `max_rows` rows, for a shape of `wbytes`-byte elements with `hl` level groups
  * per wave: the r <= max_rows that minimises rounds(r) * (r + 0.5), at most 64 for the fp64 shapes with level groups
- * (profiles/r04_rows.md).  Host arithmetic only. */
+ * (profiles/r04_rows.md).  Host arithmetic only; 0 when there is nothing to plan (no tile, row or CU). */
 int amt_march_rows_for(long ntile_i, int nj, int cus, long max_rows, int wbytes, int hl);
 /* Diagnosis: how workgroup numbers map to blocks.  0 (default): each XCD owns one contiguous run of blocks for the
  * whole launch; n > 0: every 8 n consecutive workgroup numbers cover 8 n consecutive blocks, n per XCD.  Which is

@@ -48,3 +48,8 @@ def test_rows_rule_against_brute_force(L):
         assert 1 <= got <= min(nj, max_rows)
         if wbytes == 8 and hl >= 2:
             assert got <= 64
+
+
+def test_rows_rule_refuses_empty_questions(L):
+    for args in [(0, 100, 256, 1000, 8, 1), (64, 0, 256, 1000, 8, 1), (64, 100, 0, 1000, 8, 1), (64, 100, 256, 0, 8, 1)]:
+        assert L.amt_march_rows_for(*args) == 0

@@ -1144,6 +1144,7 @@ static int amt_march_rows(long ntile_i, int nj, int cus, long max_rows, int cap,
 // the row-count rule alone, for the host-logic tests (tests/test_march_rows.py)
 extern "C" int amt_march_rows_for(long ntile_i, int nj, int cus, long max_rows, int wbytes, int hl)
 {
+    if (ntile_i < 1 || nj < 1 || cus < 1 || max_rows < 1) return 0;      // nothing to plan
     return amt_march_rows(ntile_i, nj, cus, max_rows, amt_march_rows_cap(wbytes, hl), 1, nullptr, nullptr);
 }
 
