@@ -343,7 +343,9 @@ int amt_slab_step_timed(amt_slab *slab, int n_sweeps, float *ms_total);
 int amt_slab_sync(amt_slab *slab);
 /* Test hook: from now on every sweep's exchange starts `microseconds` late on the communication stream (a device-side
  * delay in front of the ncclSend/ncclRecv group), i.e. the neighbours' rows arrive that much late -- neighbour skew on
- * one GPU with the rank as its own neighbour (AMT_SLAB_LOOPBACK; profiles/slab_loopback.py --skew-us).  0 = off. */
+ * one GPU with the rank as its own neighbour (AMT_SLAB_LOOPBACK; profiles/slab_loopback.py --skew-us).  0 = off.
+ * AMT_SLAB_SKEW_WGS=n in the environment gives the delay n workgroups that each hold a compute unit (31: what RCCL's
+ * waiting send/recv kernel holds; default 1). */
 int amt_slab_set_skew_us(amt_slab *slab, int microseconds);
 long amt_slab_halo_bytes(const amt_slab *slab);              /* sent (= received) per sweep      */
 /* rank and size as the communicator reports them (0 of 1 without one) */

@@ -367,8 +367,12 @@ int amt_slab_enqueue_exchange(amt_slab *s, hipStream_t stream)
 
 // Test hook (amt_slab_set_skew_us): holds the communication stream for `ticks` of the 100 MHz real-time counter, so that
 // the exchange behind it starts -- and the neighbours' rows arrive -- that much late: neighbour skew on one GPU.
+// AMT_SLAB_SKEW_WGS=n (default 1) gives the delay the footprint of RCCL's waiting send/recv kernel: n workgroups of 256 threads,
+// each with enough LDS to have a compute unit to itself (RCCL's 31 workgroups fit beside no march workgroup either).
 __global__ void amt_slab_delay_kernel(unsigned long long ticks)
 {
+    extern __shared__ unsigned char amt_delay_lds[];
+    if (threadIdx.x == 0) amt_delay_lds[0] = 0;
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
@@ -423,8 +427,17 @@ int amt_slab_step_t(amt_slab *s, int n_sweeps)
             rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi, true);        // interior overlaps the exchange
             if (rc) { join(); return rc; }
         }
-        if (s->skew_us > 0)
-            hipLaunchKernelGGL(amt_slab_delay_kernel, dim3(1), dim3(1), 0, edge_stream, (unsigned long long)s->skew_us * 100ull);
+        if (s->skew_us > 0) {
+            static const int wgs = [] { const char *e = getenv("AMT_SLAB_SKEW_WGS"); const int n = e ? atoi(e) : 1; return n > 1 ? n : 1; }();
+            if (wgs > 1) {
+                static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_slab_delay_kernel),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+                hipLaunchKernelGGL(amt_slab_delay_kernel, dim3(wgs), dim3(256), granted ? 96 * 1024 : 48 * 1024, edge_stream,
+                                   (unsigned long long)s->skew_us * 100ull);
+            } else {
+                hipLaunchKernelGGL(amt_slab_delay_kernel, dim3(1), dim3(1), 16, edge_stream, (unsigned long long)s->skew_us * 100ull);
+            }
+        }
         rc = amt_slab_enqueue_exchange(s, edge_stream);
         if (rc) { join(); return rc; }
         if (!s->overlap) {
