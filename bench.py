@@ -86,9 +86,14 @@ def parse():
     ap.add_argument("--launch-timeout", type=float, default=600.0,
                     help="self-launch (N > 1 without a launcher): give up and end every rank after this many seconds")
     ap.add_argument("--share-gpu", action="store_true",
-                    help="N > 1 with fewer GPUs than ranks and the RCCL transport: map ranks onto the visible devices "
-                         "anyway.  RCCL refuses two ranks on one device -- this drives the failure path (diagnosis, clean "
-                         "non-zero exit of every rank) on a one-GPU box; never a measurement")
+                    help="N > 1 with fewer GPUs than ranks: map ranks onto the visible devices anyway.  With --transport ipc "
+                         "the ranks really run (two processes, one device: a correctness run of the whole N > 1 path, never a "
+                         "scaling number); with the RCCL transport this drives the failure path (RCCL refuses two ranks on one "
+                         "device: diagnosis, clean non-zero exit of every rank)")
+    ap.add_argument("--transport", choices=("rccl", "ipc"), default="rccl",
+                    help="N > 1, native stepper: what carries the halo rows -- rccl = ncclSend/ncclRecv (north_star's transport); "
+                         "ipc = hipIpcMemHandles + a shared-memory mailbox + copy-engine pulls between the processes of one "
+                         "node (no RCCL; no compute unit held while the wire is busy; ranks may share a device)")
     ap.add_argument("--comm-timeout", type=float, default=120.0,
                     help="N > 1: most seconds a rank waits in the communicator set-up (ncclCommInitRank) and in the "
                          "first halo exchange before it ends itself with a diagnosis")
@@ -649,6 +654,8 @@ def run_rank(a):
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     a.gpus = world
+    if world > 1 and a.transport == "ipc":
+        os.environ["AMT_SLAB_TRANSPORT"] = "ipc"       # also makes amt_comm_unique_id independent of RCCL
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     ndev = torch.cuda.device_count()
@@ -758,7 +765,7 @@ def run_rank(a):
         flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if flag.item() < 0.5:
-            raise SystemExit(f"rank {rank}: RCCL is not usable for the native stepper: {err or 'another rank failed'}")
+            raise SystemExit(f"rank {rank}: no communicator id for the native stepper ({a.transport}): {err or 'another rank failed'}")
         dist.broadcast_object_list(uid, src=0)
         # phase 2, collective (ncclCommInitRank).  It runs on a helper thread under a watchdog, so that every
         # rank reaches the agreement below within --comm-timeout whatever its peers do.  Outcomes, worst over ranks:
@@ -772,8 +779,9 @@ def run_rank(a):
         stepper, state = None, 2
         try:
             stepper = watchdog(lambda: pkg.patch.NativeSlabStepper(dev, rank, world, uid[0], stream=main_stream,
-                                                                   overlap=not a.no_overlap, variant=a.variant),
-                               a.comm_timeout, "amt_slab_create (ncclCommInitRank)")
+                                                                   overlap=not a.no_overlap, variant=a.variant,
+                                                                   transport=a.transport),
+                               a.comm_timeout, "amt_slab_create (ncclCommInitRank)" if a.transport == "rccl" else "amt_slab_create (IPC set-up)")
         except StepTimeout as e:
             native_error, state = f"{e}; {where()}", 0
         except pkg.AmtError as e:
@@ -918,14 +926,16 @@ def run_rank(a):
             "dtype": a.dtype,
             "data": "synthetic (seeded closed-form WRF-shaped fields, include/amt_synth.h)",
             "config": {"workload": f"advance_mu_t {a.ni}x{a.nk}x{a.nj} (i,k,j) {a.dtype}, "
-                                   f"{world} j-slab(s), one-row RCCL halo exchange per sweep",
+                                   f"{world} j-slab(s), one-row halo exchange per sweep",
                        "ni": a.ni, "nk": a.nk, "nj": a.nj, "variant": a.variant,
                        "halo_overlap": (not a.no_overlap) if world > 1 else None,
-                       "halo_transport": ("rccl" if a.backend == "nccl" else "gloo-host-staged (bring-up)") if world > 1 else None,
+                       "halo_transport": ((stepper.transport() if native else "rccl") if a.backend == "nccl"
+                                          else "gloo-host-staged (bring-up)") if world > 1 else None,
+                       "ranks_share_a_device": bool(world > 1 and world > ndev),
                        "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep(),
                        "placement_probe_ms": probe_ms,
                        "kernel": pkg.load_library().amt_march_last_kernel().decode()},
-            "stepper": ("native amt_slab_* (C++ runtime, ncclSend/ncclRecv)" if native else
+            "stepper": ((f"native amt_slab_* (C++ runtime, {'ncclSend/ncclRecv' if a.transport == 'rccl' else 'IPC peer copies + mailbox'})") if native else
                         "torch.distributed P2P (patch.SlabStepper)") if world > 1 else "single launch per sweep",
             "ranks_seen": ranks_seen,
             "native_stepper_error": native_error,
@@ -940,6 +950,9 @@ def run_rank(a):
                          "aggregate_GBps": round(abytes / ev_per_step_s / 1e9, 1)},
             "verified_vs_oracle": verified,
         }
+        if world > 1 and world > ndev:
+            out["note"] = (f"{world} ranks share {ndev} device(s): a correctness run of the whole N > 1 path (slabs, halo exchange, "
+                           "verification, reductions); `value` is NOT a scaling measurement")
         if probe_ms and len(probe_ms) >= 2:
             # What an UN-sampled placement gives: the K probes are the same two sweeps on K
             # allocations of the same state; `value` was timed on the fastest of them.  The median probe over the

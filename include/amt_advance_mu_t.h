@@ -311,17 +311,30 @@ int amt_synth_fill_device(void *hip_stream, int field, int dtype_bytes, void *ds
  *     boundary rows then run, while the interior rows compute on the domain's stream.  Outputs
  *     need no exchange.  The reference splits j over its GPUs inside one process and refills
  *     the halos from the host on every call (advance_mu_t_no_async.cu:108-162).
- *     RCCL is loaded on first use (dlopen; AMT_RCCL_LIBRARY overrides the name).
+ *     Two transports carry the rows.  RCCL (the default; loaded on first use with dlopen, AMT_RCCL_LIBRARY overrides the
+ *     name): xGMI between the GPUs of a node; it needs one device per rank.  IPC (AMT_SLAB_TRANSPORT_IPC, or
+ *     AMT_SLAB_TRANSPORT=ipc in the environment of a host that cannot pass the flag): no RCCL at all -- at creation the
+ *     ranks trade hipIpcMemHandles of their boundary rows through a POSIX shared-memory block named after the unique id;
+ *     per sweep the receiver waits for its neighbour's "rows final" number in that block (a one-wave kernel), pulls the rows
+ *     with the copy engine (hipMemcpyAsync from the peer mapping: SDMA over xGMI between GPUs, no compute unit held while
+ *     the wire is busy -- RCCL's send/recv kernel holds 31) and posts "pulled"; a rank's sweep ends when its neighbours have
+ *     pulled its rows.  The ranks must be processes of one node; they may share ONE device (how the two-rank tests run on
+ *     a one-GPU box).  The arrays must come from hipMalloc or a pooled allocator over it (not hipMemMap ranges).
+ *     AMT_IPC_PULL=kernel pulls with one kernel launch instead of six copy-engine transfers; AMT_IPC_TIMEOUT_S (120) bounds
+ *     the host-side waits of the set-up, AMT_IPC_DEVICE_TIMEOUT_S (30) a device-side wait for a neighbour: it gives up,
+ *     the sweep completes with invalid halo rows and amt_slab_sync returns AMT_ERR_COMM (nothing ever hangs the GPU).
  * ------------------------------------------------------------------------ */
 #define AMT_UNIQUE_ID_BYTES 128              /* sizeof(ncclUniqueId) */
 enum amt_slab_flags {
     AMT_SLAB_NO_OVERLAP = 1,                 /* exchange, then all rows, on one stream          */
-    AMT_SLAB_LOOPBACK = 2                    /* one-rank test mode: both neighbours are this rank */
+    AMT_SLAB_LOOPBACK = 2,                   /* one-rank test mode: both neighbours are this rank */
+    AMT_SLAB_TRANSPORT_IPC = 4               /* peer copies between processes instead of RCCL     */
 };
 typedef struct amt_slab amt_slab;
 
 int amt_set_device(int device);              /* hipSetDevice for hosts without a HIP binding     */
-/* rank 0: a fresh communicator id (ncclGetUniqueId) to hand to every rank */
+/* rank 0: a fresh communicator id to hand to every rank: ncclGetUniqueId; where RCCL cannot be loaded, or with
+ * AMT_SLAB_TRANSPORT=ipc in the environment, random bytes that name the launch for the IPC transport only */
 int amt_comm_unique_id(void *id_out /* AMT_UNIQUE_ID_BYTES */);
 /* The same through a file for hosts without MPI.  Rank 0 creates the id and publishes it as
  * `path` behind a header carrying `nonce`; every other rank waits (up to timeout_s) for a file
@@ -333,22 +346,23 @@ int amt_comm_rendezvous_file(const char *path, uint64_t nonce, int rank, int wor
 /* a value all processes of one launch agree on and two launches do not: AMT_RENDEZVOUS_NONCE if
  * set, else the launcher (TORCHELASTIC_RUN_ID, parent pid + its start time) and MASTER_PORT */
 uint64_t amt_comm_launch_nonce(void);
-/* collective over the `world` ranks (ncclCommInitRank); the domain must outlive the slab */
+/* collective over the `world` ranks (ncclCommInitRank / the IPC set-up); the domain must outlive the slab */
 int amt_slab_create(amt_slab **out, amt_domain *domain, int rank, int world,
                     const void *unique_id, int flags);
 int amt_slab_destroy(amt_slab *slab);
 int amt_slab_exchange(amt_slab *slab);       /* the halo exchange alone                           */
 int amt_slab_step(amt_slab *slab, int n_sweeps);             /* asynchronous                      */
 int amt_slab_step_timed(amt_slab *slab, int n_sweeps, float *ms_total);
-int amt_slab_sync(amt_slab *slab);
+int amt_slab_sync(amt_slab *slab);               /* AMT_ERR_COMM if a device-side wait for a neighbour gave up (IPC) */
+const char *amt_slab_transport(const amt_slab *slab);        /* "rccl", "ipc", or "none" (a world of one)  */
 /* Test hook: from now on every sweep's exchange starts `microseconds` late on the communication stream (a device-side
  * delay in front of the ncclSend/ncclRecv group), i.e. the neighbours' rows arrive that much late -- neighbour skew on
  * one GPU with the rank as its own neighbour (AMT_SLAB_LOOPBACK; profiles/slab_loopback.py --skew-us).  0 = off.
  * AMT_SLAB_SKEW_WGS=n in the environment gives the delay n workgroups that each hold a compute unit (31: what RCCL's
  * waiting send/recv kernel holds; default 1). */
 int amt_slab_set_skew_us(amt_slab *slab, int microseconds);
-long amt_slab_halo_bytes(const amt_slab *slab);              /* sent (= received) per sweep      */
-/* rank and size as the communicator reports them (0 of 1 without one) */
+long amt_slab_halo_bytes(const amt_slab *slab);              /* sent + received by this rank per sweep */
+/* rank and size as the transport reports them: the communicator, or the ranks attached to the IPC block (0 of 1 without one) */
 int amt_slab_comm_info(const amt_slab *slab, int *rank, int *world);
 /* reporting aids for hosts without MPI: drain this rank's streams, then wait for every rank
  * (barrier) / replace *x by its maximum over the ranks.  The sweep itself has no collective. */

@@ -61,3 +61,12 @@ def bits_equal(a, b) -> bool:
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
     return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def slow_note(what: str, seconds: float, budget: float) -> None:
+    """Wall-clock is never part of a parity verdict: a run that takes longer than its budget on a
+    slow lease is reported -- printed and raised as a warning pytest lists in its summary -- and the test goes on."""
+    import warnings
+    print(f"  {what}: {seconds:.1f} s (budget {budget:.0f} s)")
+    if seconds > budget:
+        warnings.warn(f"{what} took {seconds:.1f} s, over its {budget:.0f} s budget (slow lease? not a parity failure)")

@@ -67,9 +67,10 @@ def test_world_of_one_is_the_plain_domain_step(pkg, torch_mod):
         lib.check(L.amt_domain_destroy(h))
 
 
+@pytest.mark.parametrize("transport", [0, 4], ids=["rccl", "ipc"])
 @pytest.mark.parametrize("flags", [0, 1], ids=["overlap", "no-overlap"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_loopback_exchange_and_edge_rows(pkg, torch_mod, dtype, flags):
+def test_loopback_exchange_and_edge_rows(pkg, torch_mod, dtype, flags, transport):
     """Middle slab of three; in loopback mode the rank is its own neighbour, so after the exchange
     row jte+1 of v, v_1, t_1, muv, msfvx_inv holds its own row jts and row jts-1 of t_1 its own row
     jte.  Expected result: the torch path with exactly those rows copied by hand."""
@@ -86,8 +87,9 @@ def test_loopback_exchange_and_edge_rows(pkg, torch_mod, dtype, flags):
     uid = (ctypes.c_char * 128)()
     try:
         lib.check(L.amt_comm_unique_id(uid))
-        lib.check(L.amt_slab_create(ctypes.byref(s), h, 0, 1, uid, 2 | flags))
+        lib.check(L.amt_slab_create(ctypes.byref(s), h, 0, 1, uid, 2 | flags | transport))
         assert L.amt_slab_halo_bytes(s) > 0
+        assert L.amt_slab_transport(s) == (b"ipc" if transport else b"rccl")
         # halos poisoned: only a working exchange gives the right answer
         poison = np.full(b.shape("t_1"), np.nan, dtype=dtype)
         t1 = _download(pkg, h, b, dtype, ["t_1"])["t_1"]
@@ -115,9 +117,10 @@ def test_loopback_exchange_and_edge_rows(pkg, torch_mod, dtype, flags):
         lib.check(L.amt_domain_destroy(h))
 
 
+@pytest.mark.parametrize("transport", [0, 4], ids=["rccl", "ipc"])
 @pytest.mark.parametrize("which", ["whole", "first", "last"])
 @pytest.mark.parametrize("flags", [0, 1], ids=["overlap", "no-overlap"])
-def test_loopback_on_a_slab_whose_boundary_rows_are_clipped(pkg, torch_mod, flags, which):
+def test_loopback_on_a_slab_whose_boundary_rows_are_clipped(pkg, torch_mod, flags, which, transport):
     """with specified / nested boundaries the window of an outermost slab is narrower than
     jts..jte (row jds and row jde-1 are not updated).  In loopback the rank is its own neighbour on BOTH sides,
     so such a slab has "boundary rows" that the clip removes: the one-launch edge path must not be taken (it
@@ -137,7 +140,7 @@ def test_loopback_on_a_slab_whose_boundary_rows_are_clipped(pkg, torch_mod, flag
     uid = (ctypes.c_char * 128)()
     try:
         lib.check(L.amt_comm_unique_id(uid))
-        lib.check(L.amt_slab_create(ctypes.byref(s), h, 0, 1, uid, 2 | flags))
+        lib.check(L.amt_slab_create(ctypes.byref(s), h, 0, 1, uid, 2 | flags | transport))
         lib.check(L.amt_slab_step(s, 5))
         lib.check(L.amt_slab_sync(s))
         want = S.make_patch(b, cfg, dtype=dtype, seed=seed, global_dims=gdims, device="cuda:0")
@@ -330,4 +333,6 @@ def test_neighbour_skew_delays_the_edges_not_the_bits(pkg, torch_mod, overlap):
     for n in S.OUTPUTS:
         assert np.isfinite(results[1][n][1:-1]).all(), n
         assert bits_equal(results[0][n], results[1][n]), n
-    assert times[1] > times[0] + 2.0e-3, times                     # a 3 ms skew on a 20 us slab shows up almost in full
+    # the timing side of the hook (a 3 ms skew on a 20 us slab shows up almost in full) is checked in
+    # tests/test_gpu_95_timing.py: no wall-clock assert in a file that judges bits
+    print(f"  sweep without / with a 3 ms skew: {times[0] * 1e3:.3f} / {times[1] * 1e3:.3f} ms")

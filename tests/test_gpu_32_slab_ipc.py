@@ -1,0 +1,93 @@
+"""Row (e) with more than one REAL rank on a GPU: `world` processes share cuda:0, each owns one j-slab in the native
+stepper (amt_slab_*), and the halo rows travel through the IPC transport (hipIpcMemHandles + a shared-memory mailbox +
+copy-engine pulls; RCCL refuses two ranks on one device).  Halos are NaN-poisoned, so only a working in-step exchange
+gives the bits of the UNSPLIT oracle run over the whole domain (what the halo must contain:
+advance_mu_t_no_async.cu:121-162; module_small_step_em.f90:143-144,241-242)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+ROOT = Path(__file__).resolve().parent.parent
+WORKER = ROOT / "tests" / "workers" / "slab_ipc_rank.py"
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(tmp_path, world, dims, *, dtype="f64", sweeps=2, overlap=True, specified=False, extra_env=None, seed=11):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(AMT_RENDEZVOUS_NONCE=f"ipc-{tmp_path.name}", AMT_SLAB_TRANSPORT="ipc", AMT_IPC_DEVICE_TIMEOUT_S="20",
+               AMT_IPC_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    procs = []
+    for r in range(world):
+        cmd = [sys.executable, str(WORKER), "--rank", str(r), "--world", str(world), "--dir", str(tmp_path), "--dims",
+               *map(str, dims), "--dtype", dtype, "--sweeps", str(sweeps), "--seed", str(seed)]
+        cmd += [] if overlap else ["--no-overlap"]
+        cmd += ["--specified"] if specified else []
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=420)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung:\n" + "\n".join(outs))
+    assert [p.returncode for p in procs] == [0] * world, "\n".join(outs)
+    return outs
+
+
+def _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, world, dims, dtype, sweeps, specified=False, seed=11):
+    S = pkg.synth
+    np_dtype = np.float64 if dtype == "f64" else np.float32
+    gb = S.domain_bounds(*dims, aligned=True)
+    want = S.make_patch(gb, pkg.GridConfig(specified=specified), dtype=np_dtype, seed=seed, global_dims=dims)
+    for _ in range(sweeps):
+        oracle.advance_mu_t_omp(*want.args(), nthreads=min(8, os.cpu_count() or 1))
+    for r in range(world):
+        sb = S.slab_bounds(gb, r, world)
+        for n in S.OUTPUTS:
+            got = np.load(tmp_path / f"out_{r}_{n}.npy")
+            assert bits_equal(got, want.arrays[n][sb.jts - gb.jms: sb.jte + 1 - gb.jms]), f"rank {r}: {n} differs from the unsplit oracle run"
+
+
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "no-overlap"])
+def test_two_processes_on_one_device_at_4096x60x64_per_rank(pkg, oracle, tmp_path, overlap):
+    dims = (4096, 60, 128)
+    outs = _run_ranks(tmp_path, 2, dims, overlap=overlap)
+    assert all("transport ipc, ranks seen 2" in o for o in outs), outs
+    _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 2, dims, "f64", 2)
+
+
+def test_three_processes_uneven_rows_specified_boundaries_fp32(pkg, oracle, tmp_path):
+    """The middle rank has both neighbours; 61 rows over 3 ranks; `specified` clips the outermost rows."""
+    dims = (300, 24, 61)
+    _run_ranks(tmp_path, 3, dims, dtype="f32", sweeps=3, specified=True)
+    _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 3, dims, "f32", 3, specified=True)
+
+
+def test_pull_by_one_kernel_instead_of_the_copy_engine(pkg, oracle, tmp_path):
+    dims = (515, 33, 40)                   # rows that are not a multiple of 16 bytes: the pull kernel's tail
+    _run_ranks(tmp_path, 2, dims, dtype="f32", extra_env={"AMT_IPC_PULL": "kernel"})
+    _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 2, dims, "f32", 2)
+
+
+def test_a_missing_neighbour_ends_with_a_diagnosis_not_a_hang(pkg, tmp_path):
+    """Rank 1 of 2 never starts: rank 0's set-up gives up after AMT_IPC_TIMEOUT_S with AMT_ERR_COMM (non-zero exit, text)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(AMT_RENDEZVOUS_NONCE=f"ipc-{tmp_path.name}", AMT_SLAB_TRANSPORT="ipc", AMT_IPC_TIMEOUT_S="5")
+    # give rank 0 its id without a peer: a pre-made rendezvous is not possible, so start rank 1 and let it die before the set-up
+    code = ("import sys, ctypes; sys.path.insert(0, %r); import __graft_entry__ as g; pkg = g.load_package(); L = pkg.load_library();"
+            "uid = (ctypes.c_char * 128)(); pkg.lib.check(L.amt_comm_rendezvous_file(%r.encode(), 0, 1, 2, 60.0, uid))"
+            % (str(ROOT), str(tmp_path / "uid")))
+    quitter = subprocess.Popen([sys.executable, "-c", code], env=env)
+    r = subprocess.run([sys.executable, str(WORKER), "--rank", "0", "--world", "2", "--dir", str(tmp_path), "--dims", "64", "10", "16"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    quitter.wait(timeout=60)
+    assert r.returncode != 0
+    assert "did not publish" in r.stdout + r.stderr or "ranks attached" in r.stdout + r.stderr, r.stdout[-1500:] + r.stderr[-1500:]

@@ -57,6 +57,17 @@ def test_three_ranks_uneven_split():
     assert out["n_gpus"] == 3 and out["verified_vs_oracle"] is True
 
 
+def test_native_stepper_two_processes_share_the_gpu_over_the_ipc_transport():
+    """the native stepper with two REAL ranks on this box's one GPU -- halo rows by IPC peer
+    copies, every rank verified against the oracle, the ranks counted by the transport itself."""
+    out = _run(["--gpus", "2", "--share-gpu", "--transport", "ipc", "--probe-placements", "1", "--no-box-probe"] + SMALL)
+    assert out["stepper"].startswith("native") and out["ranks_seen"] == 2
+    assert out["verified_vs_oracle"] is True
+    assert out["config"]["halo_transport"] == "ipc" and out["config"]["ranks_share_a_device"] is True
+    assert out["config"]["halo_bytes_per_rank_per_sweep"] > 0
+    assert "NOT a scaling measurement" in out["note"]
+
+
 def test_native_stepper_with_two_real_ranks():
     if _gpus() < 2:
         pytest.skip("RCCL needs one GPU per rank: fewer than two devices visible")

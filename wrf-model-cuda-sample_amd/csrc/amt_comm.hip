@@ -1,0 +1,764 @@
+// amt_comm.hip -- what the multi-rank steppers share: the RCCL loader, the communicator id and its file rendezvous
+// (include/amt_advance_mu_t.h section 5) and the halo-exchange engine with its two transports (amt_comm.h).
+#include "amt_comm.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+// ---------------------------------------------------------------------------
+// RCCL is opened with dlopen on first use: the library has no link-time dependency on it and
+// single-GPU users never load it.
+// ---------------------------------------------------------------------------
+namespace {
+struct AmtRccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+AmtRccl g_rccl;
+std::mutex g_rccl_mutex;
+
+int amt_rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mutex);
+    if (g_rccl.lib) return AMT_OK;
+    const char *names[] = {getenv("AMT_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names)
+        if (n && *n && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!lib) return amt_fail(AMT_ERR_COMM, "cannot open librccl: %s", dlerror());
+    AmtRccl r;
+    r.lib = lib;
+    bool ok = true;
+    auto sym = [&](const char *name) { void *p = dlsym(lib, name); ok = ok && p; return p; };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(lib); return amt_fail(AMT_ERR_COMM, "librccl lacks a send/recv entry point"); }
+    g_rccl = r;
+    return AMT_OK;
+}
+}  // namespace
+
+#define AMT_NCCL(call)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return amt_fail(AMT_ERR_COMM, "%s failed: %s (%s:%d)", #call,                       \
+                            g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", __FILE__, __LINE__); \
+    } while (0)
+
+static_assert(AMT_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "amt_comm_unique_id hands out an ncclUniqueId");
+
+extern "C" int amt_set_device(int device)
+{
+    AMT_HIP(hipSetDevice(device));
+    return AMT_OK;
+}
+
+namespace {
+struct AmtRendezvousHeader {
+    char magic[8];
+    uint64_t nonce;
+};
+const char kRvMagic[8] = {'A', 'M', 'T', 'U', 'I', 'D', '0', '2'};
+
+uint64_t amt_fnv1a(uint64_t h, const void *data, size_t n)
+{
+    const unsigned char *q = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= q[i]; h *= 1099511628211ull; }
+    return h;
+}
+}  // namespace
+
+// Ids made without RCCL (it could not be loaded, or AMT_SLAB_TRANSPORT=ipc asks for none of it) start with this word:
+// they name a launch for the IPC transport and are refused by the RCCL one.
+static const char kLocalIdMagic[8] = {'A', 'M', 'T', 'L', 'O', 'C', 'I', 'D'};
+
+static bool amt_env_transport_is_ipc()
+{
+    const char *e = getenv("AMT_SLAB_TRANSPORT");
+    return e && !strcmp(e, "ipc");
+}
+
+extern "C" int amt_comm_unique_id(void *id_out)
+{
+    if (!id_out) return amt_fail(AMT_ERR_INVALID_ARG, "null id buffer");
+    if (!amt_env_transport_is_ipc() && amt_rccl_load() == AMT_OK) {
+        ncclUniqueId id;
+        AMT_NCCL(g_rccl.GetUniqueId(&id));
+        memcpy(id_out, &id, sizeof id);
+        return AMT_OK;
+    }
+    // no RCCL: 120 random bytes behind the magic word (enough to name one launch on one node)
+    unsigned char *q = static_cast<unsigned char *>(id_out);
+    memcpy(q, kLocalIdMagic, 8);
+    size_t got = 0;
+    if (FILE *f = fopen("/dev/urandom", "rb")) {
+        got = fread(q + 8, 1, AMT_UNIQUE_ID_BYTES - 8, f);
+        fclose(f);
+    }
+    if (got != AMT_UNIQUE_ID_BYTES - 8) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        uint64_t h = amt_fnv1a(1469598103934665603ull, &ts, sizeof ts);
+        const long pid = (long)getpid();
+        for (size_t k = 8; k < AMT_UNIQUE_ID_BYTES; k += 8) {
+            h = amt_fnv1a(h, &pid, sizeof pid);
+            memcpy(q + k, &h, 8);
+        }
+    }
+    return AMT_OK;
+}
+
+// Rendezvous for hosts without MPI: rank 0 creates the id and publishes it as `path` (written
+// under a temporary name, then renamed) behind a header that carries the LAUNCH NONCE; the other
+// ranks wait for a file whose nonce is theirs, read the id and acknowledge with `path.ack.<rank>`;
+// rank 0 waits for the world-1 acknowledgements and removes every file.  A file left behind by an
+// earlier launch (a crashed one: a completed one leaves nothing) carries another nonce and is
+// never taken for this launch's, however recently it was written.
+
+// A value every process of ONE launch computes identically and two launches do not share:
+// AMT_RENDEZVOUS_NONCE if set; else a job id the scheduler gives every rank of the job (SLURM_JOB_ID +
+// step, PMI / PMIx / Open MPI job ids, LSB_JOBID, PBS_JOBID) -- such ranks need not share a parent
+// process (one srun / orted daemon per node) -- together with MASTER_PORT; else the parent process (pid and
+// start time from /proc: the ranks of a local launch are children of one launcher) together with MASTER_PORT.
+// A LOCAL launcher inside either (TORCHELASTIC_RUN_ID is set: torchrun started the ranks of this node) adds
+// its run id, its restart count and itself as the parent process: two torchrun launches inside one
+// allocation, or an elastic restart on the same port, then differ although the scheduler's ids do not
+// (without that, ranks >= 1 of the second launch accepted the file a crashed first one left).
+// Ranks started by hand (a shell or ssh per rank) have neither a job id nor a common parent, and ranks of
+// several torchrun agents that share the rendezvous file over a network file system have different parents:
+// both must be given AMT_RENDEZVOUS_NONCE.  Never 0.
+// several launcher agents (torchrun per node) make up this launch: the ranks do not share a parent process
+static bool amt_launch_spans_agents()
+{
+    const char *lw = getenv("LOCAL_WORLD_SIZE"), *w = getenv("WORLD_SIZE"), *el = getenv("TORCHELASTIC_RUN_ID");
+    return el && *el && lw && *lw && w && *w && atol(lw) != atol(w);
+}
+
+extern "C" uint64_t amt_comm_launch_nonce(void)
+{
+    uint64_t h = 1469598103934665603ull;
+    static const char *const job_ids[] = {"SLURM_JOB_ID", "SLURM_STEP_ID", "PMI_JOBID", "PMI_ID_JOB", "PMIX_NAMESPACE",
+                                          "OMPI_MCA_ess_base_jobid", "LSB_JOBID", "PBS_JOBID"};
+    auto mix_env = [&](const char *name) {
+        if (const char *t = getenv(name); t && *t) { h = amt_fnv1a(h, name, strlen(name)); h = amt_fnv1a(h, t, strlen(t)); }
+    };
+    auto mix_parent = [&] {
+        const long ppid = (long)getppid();
+        h = amt_fnv1a(h, &ppid, sizeof ppid);
+        char statpath[64];
+        snprintf(statpath, sizeof statpath, "/proc/%ld/stat", ppid);
+        if (FILE *f = fopen(statpath, "r")) {
+            char buf[1024];
+            const size_t n = fread(buf, 1, sizeof buf - 1, f);
+            fclose(f);
+            buf[n] = 0;
+            // field 22 (starttime) counted after the last ')' of the command name
+            if (const char *q = strrchr(buf, ')')) {
+                int field = 2;
+                for (++q; *q && field < 22; ++q)
+                    if (*q == ' ') ++field;
+                const char *e = q;
+                while (*e && *e != ' ') ++e;
+                h = amt_fnv1a(h, q, (size_t)(e - q));
+            }
+        }
+    };
+    bool have_job = false;
+    for (const char *name : job_ids)
+        if (const char *t = getenv(name); t && *t) have_job = true;
+    const char *elastic = getenv("TORCHELASTIC_RUN_ID");
+    const bool local_launcher = elastic && *elastic;
+    if (const char *s = getenv("AMT_RENDEZVOUS_NONCE"); s && *s) {
+        h = amt_fnv1a(h, s, strlen(s));
+        return h ? h : 1;
+    }
+    if (have_job)
+        for (const char *name : job_ids) mix_env(name);
+    if (local_launcher) {
+        mix_env("TORCHELASTIC_RUN_ID");
+        mix_env("TORCHELASTIC_RESTART_COUNT");
+    }
+    // the launcher's run id alone may be a fixed word ("none" for a static rendezvous): the parent process as well,
+    // unless the scheduler's ids are all there is to agree on (its ranks have one daemon per node as parents) -- or the
+    // local launcher is one of SEVERAL (one torchrun agent per node under a scheduler, LOCAL_WORLD_SIZE < WORLD_SIZE:
+    // the ranks of the other nodes have other parents; what all nodes share is the job id, the run id and the master's
+    // address)
+    if (amt_launch_spans_agents()) mix_env("MASTER_ADDR");
+    else if (!have_job || local_launcher) mix_parent();
+    mix_env("MASTER_PORT");
+    return h ? h : 1;
+}
+
+extern "C" int amt_comm_rendezvous_file(const char *path, uint64_t nonce, int rank, int world,
+                                        double timeout_s, void *id_out)
+{
+    if (!path || !*path || !id_out || rank < 0 || world < 1 || rank >= world)
+        return amt_fail(AMT_ERR_INVALID_ARG, "bad rendezvous argument");
+    if (nonce == 0) {
+        // several launcher agents and nothing all of them share (no scheduler job id, no explicit nonce): their ranks would
+        // compute different nonces and time out on each other's file -- say so now
+        static const char *const shared[] = {"AMT_RENDEZVOUS_NONCE", "SLURM_JOB_ID", "PMI_JOBID", "PMI_ID_JOB", "PMIX_NAMESPACE",
+                                             "OMPI_MCA_ess_base_jobid", "LSB_JOBID", "PBS_JOBID"};
+        bool any = false;
+        for (const char *n : shared)
+            if (const char *t = getenv(n); t && *t) any = true;
+        if (!any && amt_launch_spans_agents() && !(getenv("TORCHELASTIC_RUN_ID") && strcmp(getenv("TORCHELASTIC_RUN_ID"), "none")))
+            return amt_fail(AMT_ERR_COMM, "this launch spans several launcher agents (LOCAL_WORLD_SIZE %s of WORLD_SIZE %s) without a scheduler "
+                                          "job id or a run id they share: export the same AMT_RENDEZVOUS_NONCE to every rank",
+                            getenv("LOCAL_WORLD_SIZE"), getenv("WORLD_SIZE"));
+        nonce = amt_comm_launch_nonce();
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto waited = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    auto ack_name = [&](int r) { return std::string(path) + ".ack." + std::to_string(r); };
+    if (rank == 0) {
+        (void)unlink(path);
+        for (int r = 1; r < world; ++r) (void)unlink(ack_name(r).c_str());
+        int rc = amt_comm_unique_id(id_out);
+        if (rc) return rc;
+        AmtRendezvousHeader hd;
+        memcpy(hd.magic, kRvMagic, 8);
+        hd.nonce = nonce;
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) return amt_fail(AMT_ERR_COMM, "cannot write %s", tmp.c_str());
+        const size_t n = fwrite(&hd, 1, sizeof hd, f) + fwrite(id_out, 1, AMT_UNIQUE_ID_BYTES, f);
+        fclose(f);
+        if (n != sizeof hd + AMT_UNIQUE_ID_BYTES || rename(tmp.c_str(), path) != 0)
+            return amt_fail(AMT_ERR_COMM, "cannot publish %s", path);
+        // wait until every other rank of THIS launch has the id, then leave nothing behind
+        for (int r = 1; r < world; ++r) {
+            const std::string an = ack_name(r);
+            for (;;) {
+                uint64_t got = 0;
+                if (FILE *g = fopen(an.c_str(), "rb")) {
+                    const size_t m = fread(&got, 1, sizeof got, g);
+                    fclose(g);
+                    if (m == sizeof got && got == nonce) break;
+                }
+                if (waited() > timeout_s) {
+                    (void)unlink(path);
+                    return amt_fail(AMT_ERR_COMM, "rank %d did not pick up %s within %.0f s", r, path, timeout_s);
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            }
+            (void)unlink(an.c_str());
+        }
+        (void)unlink(path);
+        return AMT_OK;
+    }
+    bool saw_stale = false;
+    for (;;) {
+        if (FILE *f = fopen(path, "rb")) {
+            AmtRendezvousHeader hd;
+            char id[AMT_UNIQUE_ID_BYTES];
+            const size_t n = fread(&hd, 1, sizeof hd, f) + fread(id, 1, sizeof id, f);
+            fclose(f);
+            if (n == sizeof hd + sizeof id && memcmp(hd.magic, kRvMagic, 8) == 0) {
+                if (hd.nonce == nonce) {
+                    memcpy(id_out, id, sizeof id);
+                    const std::string an = ack_name(rank), tmp = an + ".tmp";
+                    FILE *g = fopen(tmp.c_str(), "wb");
+                    if (!g) return amt_fail(AMT_ERR_COMM, "cannot write %s", tmp.c_str());
+                    const size_t m = fwrite(&nonce, 1, sizeof nonce, g);
+                    fclose(g);
+                    if (m != sizeof nonce || rename(tmp.c_str(), an.c_str()) != 0)
+                        return amt_fail(AMT_ERR_COMM, "cannot acknowledge %s", path);
+                    return AMT_OK;
+                }
+                saw_stale = true;          // another launch's file: rank 0 of this one will replace it
+            }
+        }
+        if (waited() > timeout_s)
+            return amt_fail(AMT_ERR_COMM, saw_stale ? "%s belongs to another launch (nonce mismatch) after %.0f s; ranks that do not share "
+                                                      "a parent process or a scheduler job id need the same AMT_RENDEZVOUS_NONCE"
+                                                    : "no rendezvous file %s after %.0f s", path, timeout_s);
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the exchange engine (amt_comm.h)
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kMaxExports = 16;          // send segments of one rank (a grid patch has 12)
+constexpr int kMaxPeers = 4;             // below, above, left, right
+constexpr uint64_t kShmMagic = 0x414d54584348470aull;       // "AMTXCHG\n"
+
+struct ShmExport {
+    hipIpcMemHandle_t handle;            // of the ALLOCATION the segment lies in (hipMemGetAddressRange)
+    uint64_t offset;                     // of the segment inside it
+    uint64_t bytes;
+    int32_t dest;
+    int32_t pad;
+};
+
+// Everything two ranks share, in one POSIX shared-memory block every rank registers with hipHostRegister: the device
+// kernels below poll and post the sequence numbers through it (fine-grained host memory: coherent for both processes
+// and for every GPU of the node), the hosts use the header for the set-up rendezvous, the barrier and the max.
+struct ShmHeader {
+    uint64_t magic;
+    uint32_t world;
+    uint32_t rank_bytes;
+    std::atomic<uint32_t> attached;      // ranks that have opened every handle they need
+    std::atomic<uint32_t> bar_count;
+    std::atomic<uint32_t> bar_gen;
+    uint32_t pad[9];
+};
+struct ShmRank {
+    std::atomic<uint32_t> published;     // 1: device, pid and exports[] are valid
+    int32_t pid;
+    int32_t nexports;
+    int32_t device;
+    char bus_id[32];
+    ShmExport exports[kMaxExports];
+    alignas(64) double red;              // amt_exchange_max
+    alignas(64) unsigned long long ready;        // posted by this rank's device: its send segments are final for exchange n
+    alignas(64) unsigned int error;              // set by this rank's own device-side waits when they give up
+    alignas(64) unsigned long long pulled[1];    // [world]: pulled[p] is posted by rank p's device: p has pulled exchange n
+};
+
+static_assert(sizeof(ShmHeader) == 64, "one line");
+
+struct AmtDevPtrs {
+    unsigned long long *p[kMaxPeers];
+    int n;
+};
+
+// "my send segments are final for exchange n", then wait until every source's are.  One wave; lane l polls source l.
+__global__ void amt_xchg_post_and_wait(unsigned long long *mine, AmtDevPtrs src, unsigned long long n,
+                                       unsigned long long ticks, unsigned int *err)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(mine, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)threadIdx.x < src.n) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(src.p[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < n) {
+            if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+}
+__global__ void amt_xchg_post(AmtDevPtrs dst, unsigned long long n)
+{
+    if ((int)threadIdx.x < dst.n) __hip_atomic_store(dst.p[threadIdx.x], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void amt_xchg_wait(AmtDevPtrs src, unsigned long long n, unsigned long long ticks, unsigned int *err)
+{
+    if ((int)threadIdx.x < src.n) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(src.p[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < n) {
+            if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+}
+
+// The pull as ONE kernel instead of one copy-engine transfer per segment (AMT_IPC_PULL=kernel): blockIdx.y = segment,
+// 16 bytes per lane.  Between GPUs it needs compute units for as long as the wire takes -- what the copy engine avoids;
+// on ONE shared device it is the faster of the two (profiles/r05_ipc_probe.txt).
+typedef unsigned int amt_v4u __attribute__((ext_vector_type(4)));
+struct AmtPullSegs {
+    const void *src[kMaxExports];
+    void *dst[kMaxExports];
+    unsigned long long bytes[kMaxExports];
+};
+__global__ __launch_bounds__(256) void amt_xchg_pull(AmtPullSegs g)
+{
+    const size_t n16 = g.bytes[blockIdx.y] / 16;
+    const amt_v4u *src = static_cast<const amt_v4u *>(g.src[blockIdx.y]);
+    amt_v4u *dst = static_cast<amt_v4u *>(g.dst[blockIdx.y]);
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n16; e += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + e), dst + e);
+    // a tail that is not a multiple of 16 bytes (rows are multiples of the element size only)
+    const size_t tail0 = n16 * 16, tail = g.bytes[blockIdx.y] - tail0;
+    if (blockIdx.x == 0 && threadIdx.x < tail)
+        static_cast<unsigned char *>(g.dst[blockIdx.y])[tail0 + threadIdx.x] = static_cast<const unsigned char *>(g.src[blockIdx.y])[tail0 + threadIdx.x];
+}
+
+double amt_env_seconds(const char *name, double dflt)
+{
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const double v = atof(e);
+    return v > 0 ? v : dflt;
+}
+
+std::mutex g_xchg_mutex;
+std::map<uint64_t, unsigned> g_xchg_instances;      // unique id -> exchanges this process has created with it
+}  // namespace
+
+struct AmtExchange {
+    int transport = AMT_XCHG_RCCL;
+    int rank = 0, world = 1, device = 0;
+    bool self_loop = false;
+    std::vector<AmtSeg> sends, recvs;
+    // RCCL
+    ncclComm_t comm = nullptr;
+    double *red = nullptr;
+    // IPC
+    void *shm = nullptr;
+    size_t shm_bytes = 0;
+    bool shm_registered = false;
+    char *shm_dev = nullptr;                 // the block as the device addresses it
+    std::vector<void *> opened;              // hipIpcOpenMemHandle mappings to close
+    std::vector<const void *> recv_src;      // per receive segment: where to pull it from
+    std::vector<int> sources, dests;         // distinct peer ranks
+    unsigned long long seq = 0;              // exchanges enqueued so far
+    unsigned long long released = 0;
+    bool pull_kernel = false;
+    unsigned long long ticks = 0;
+    double host_timeout = 120.0;
+
+    ShmHeader *hdr() const { return static_cast<ShmHeader *>(shm); }
+    ShmRank *slot(int r) const { return reinterpret_cast<ShmRank *>(static_cast<char *>(shm) + sizeof(ShmHeader) + (size_t)r * hdr()->rank_bytes); }
+    template <typename Q> Q *dev(Q *host_ptr) const { return reinterpret_cast<Q *>(shm_dev + (reinterpret_cast<char *>(host_ptr) - static_cast<char *>(shm))); }
+};
+
+namespace {
+int amt_ipc_barrier(AmtExchange *x)
+{
+    ShmHeader *h = x->hdr();
+    const uint32_t gen = h->bar_gen.load(std::memory_order_acquire);
+    if (h->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)x->world) {
+        h->bar_count.store(0, std::memory_order_relaxed);
+        h->bar_gen.store(gen + 1, std::memory_order_release);
+        return AMT_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (h->bar_gen.load(std::memory_order_acquire) == gen) {
+        if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > x->host_timeout)
+            return amt_fail(AMT_ERR_COMM, "IPC barrier: %u of %d ranks arrived within %.0f s", h->bar_count.load(), x->world, x->host_timeout);
+    }
+    return AMT_OK;
+}
+
+int amt_ipc_setup(AmtExchange *x, const void *unique_id)
+{
+    const int world = x->world, rank = x->rank;
+    if ((int)x->sends.size() > kMaxExports || (int)x->recvs.size() > kMaxExports)
+        return amt_fail(AMT_ERR_INVALID_ARG, "more than %d segments per rank", kMaxExports);
+    auto distinct = [](const std::vector<AmtSeg> &v) {
+        std::vector<int> p;
+        for (const AmtSeg &s : v)
+            if (std::find(p.begin(), p.end(), s.peer) == p.end()) p.push_back(s.peer);
+        return p;
+    };
+    x->sources = distinct(x->recvs);
+    x->dests = distinct(x->sends);
+    if ((int)x->sources.size() > kMaxPeers || (int)x->dests.size() > kMaxPeers)
+        return amt_fail(AMT_ERR_INVALID_ARG, "more than %d neighbours", kMaxPeers);
+    x->host_timeout = amt_env_seconds("AMT_IPC_TIMEOUT_S", 120.0);
+    x->ticks = (unsigned long long)(amt_env_seconds("AMT_IPC_DEVICE_TIMEOUT_S", 30.0) * 1e8);     // 100 MHz wall clock
+    if (const char *e = getenv("AMT_IPC_PULL")) x->pull_kernel = !strcmp(e, "kernel");
+
+    // the block: one name per (unique id, how many exchanges this process made with it before) -- every rank creates
+    // its exchanges in the same order, so the counters agree; whoever comes first creates it, rank 0 removes the name
+    // once every rank is attached
+    uint64_t idh = amt_fnv1a(1469598103934665603ull, unique_id, AMT_UNIQUE_ID_BYTES);
+    unsigned instance;
+    {
+        std::lock_guard<std::mutex> lk(g_xchg_mutex);
+        instance = g_xchg_instances[idh]++;
+    }
+    char name[80];
+    snprintf(name, sizeof name, "/amt_xchg_%016llx_%u", (unsigned long long)idh, instance);
+    const size_t rank_bytes = (sizeof(ShmRank) + (size_t)world * sizeof(unsigned long long) + 63) / 64 * 64;
+    x->shm_bytes = (sizeof(ShmHeader) + rank_bytes * world + 4095) / 4096 * 4096;
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) return amt_fail(AMT_ERR_COMM, "shm_open(%s) failed: %s", name, strerror(errno));
+    if (ftruncate(fd, (off_t)x->shm_bytes) != 0) { close(fd); return amt_fail(AMT_ERR_COMM, "ftruncate(%s) failed: %s", name, strerror(errno)); }
+    void *m = mmap(nullptr, x->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return amt_fail(AMT_ERR_COMM, "mmap(%s) failed: %s", name, strerror(errno));
+    x->shm = m;
+    struct Unlinker { const char *n; bool armed; ~Unlinker() { if (armed) (void)shm_unlink(n); } } unlinker{name, rank == 0};
+    ShmHeader *h = x->hdr();
+    h->world = (uint32_t)world;                  // every rank writes the same values into the zero-filled block
+    h->rank_bytes = (uint32_t)rank_bytes;
+    h->magic = kShmMagic;
+    AMT_HIP(hipHostRegister(m, x->shm_bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    x->shm_registered = true;
+    void *dptr = nullptr;
+    AMT_HIP(hipHostGetDevicePointer(&dptr, m, 0));
+    x->shm_dev = static_cast<char *>(dptr);
+
+    // publish my send segments
+    ShmRank *me = x->slot(rank);
+    me->pid = (int32_t)getpid();
+    me->device = x->device;
+    (void)hipDeviceGetPCIBusId(me->bus_id, (int)sizeof me->bus_id, x->device);
+    me->nexports = (int32_t)x->sends.size();
+    for (size_t k = 0; k < x->sends.size(); ++k) {
+        ShmExport &e = me->exports[k];
+        e.dest = x->sends[k].peer;
+        e.bytes = x->sends[k].bytes;
+        e.offset = 0;
+        if (x->self_loop) continue;               // the rank's own pointers serve: nothing to open
+        void *base = nullptr;
+        size_t size = 0;
+        // the handle is of the whole allocation (a handle taken from an inner address opens at the base as well:
+        // profiles/r05_ipc_probe.txt), the offset travels beside it
+        AMT_HIP(hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, x->sends[k].ptr));
+        e.offset = (uint64_t)(static_cast<char *>(x->sends[k].ptr) - static_cast<char *>(base));
+        if (e.offset + e.bytes > size) return amt_fail(AMT_ERR_INVALID_ARG, "send segment %zu leaves its allocation", k);
+        hipError_t he = hipIpcGetMemHandle(&e.handle, base);
+        if (he != hipSuccess)
+            return amt_fail(AMT_ERR_COMM, "hipIpcGetMemHandle failed for send segment %zu: %s (arrays from hipMalloc or a pooled "
+                                          "allocator can be shared; virtual-memory (hipMemMap) ranges cannot)", k, hipGetErrorString(he));
+    }
+    me->published.store(1, std::memory_order_release);
+
+    // open what I receive: the k-th receive from p is the k-th segment p sends to me
+    const auto t0 = std::chrono::steady_clock::now();
+    auto waited = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    x->recv_src.assign(x->recvs.size(), nullptr);
+    std::map<std::string, void *> mapped;        // one mapping per allocation
+    for (int p : x->sources) {
+        if (p < 0 || p >= world) return amt_fail(AMT_ERR_INVALID_ARG, "receive from rank %d of %d", p, world);
+        ShmRank *src = x->slot(p);
+        while (!src->published.load(std::memory_order_acquire)) {
+            if (waited() > x->host_timeout)
+                return amt_fail(AMT_ERR_COMM, "rank %d did not publish its halo rows in %s within %.0f s (AMT_IPC_TIMEOUT_S)", p, name, x->host_timeout);
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        int nth = 0;
+        for (size_t r = 0; r < x->recvs.size(); ++r) {
+            if (x->recvs[r].peer != p) continue;
+            const int kth = nth++;
+            int seen = 0, found = -1;
+            for (int k = 0; k < src->nexports; ++k)
+                if (src->exports[k].dest == rank && seen++ == kth) { found = k; break; }
+            if (found < 0) return amt_fail(AMT_ERR_COMM, "rank %d sends fewer segments to rank %d than it expects", p, rank);
+            const ShmExport &e = src->exports[found];
+            if (e.bytes != x->recvs[r].bytes)
+                return amt_fail(AMT_ERR_COMM, "segment sizes differ between rank %d (%llu bytes) and rank %d (%zu bytes)", p,
+                                (unsigned long long)e.bytes, rank, x->recvs[r].bytes);
+            if (x->self_loop) {
+                int seen_s = 0;
+                for (const AmtSeg &s : x->sends)
+                    if (s.peer == rank && seen_s++ == kth) { x->recv_src[r] = s.ptr; break; }
+                continue;
+            }
+            const std::string key(reinterpret_cast<const char *>(&e.handle), sizeof e.handle);
+            auto it = mapped.find(key);
+            if (it == mapped.end()) {
+                void *q = nullptr;
+                hipError_t he = hipIpcOpenMemHandle(&q, e.handle, hipIpcMemLazyEnablePeerAccess);
+                if (he != hipSuccess)
+                    return amt_fail(AMT_ERR_COMM, "hipIpcOpenMemHandle of rank %d's rows failed: %s (pid %d, device %s; "
+                                                  "HSA_ENABLE_IPC_MODE_LEGACY=%s)", p, hipGetErrorString(he), (int)src->pid, src->bus_id,
+                                    getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "unset");
+                x->opened.push_back(q);
+                it = mapped.emplace(key, q).first;
+            }
+            x->recv_src[r] = static_cast<char *>(it->second) + e.offset;
+        }
+    }
+    // everybody attached: the name can go (the mappings stay)
+    h->attached.fetch_add(1, std::memory_order_acq_rel);
+    while (h->attached.load(std::memory_order_acquire) < (uint32_t)world) {
+        if (waited() > x->host_timeout)
+            return amt_fail(AMT_ERR_COMM, "%u of %d ranks attached to %s within %.0f s", h->attached.load(), world, name, x->host_timeout);
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    return AMT_OK;
+}
+
+int amt_rccl_exchange(AmtExchange *x, hipStream_t stream)
+{
+    // per pair of ranks the order of sends matches the order of receives on the other side.  A failing call must not
+    // leave the group open (every later RCCL call of this thread would be queued into it, the communicator's destruction
+    // included): remember the first error and always close the group.
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    auto note = [&](ncclResult_t r, const char *w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; what = w; } };
+    AMT_NCCL(g_rccl.GroupStart());
+    for (const AmtSeg &s : x->sends) note(g_rccl.Send(s.ptr, s.bytes, ncclChar, s.peer, x->comm, stream), "ncclSend");
+    for (const AmtSeg &s : x->recvs) note(g_rccl.Recv(s.ptr, s.bytes, ncclChar, s.peer, x->comm, stream), "ncclRecv");
+    note(g_rccl.GroupEnd(), "ncclGroupEnd");
+    if (first != ncclSuccess)
+        return amt_fail(AMT_ERR_COMM, "%s failed in the halo exchange: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(first) : "?");
+    return AMT_OK;
+}
+}  // namespace
+
+int amt_exchange_destroy(AmtExchange *x)
+{
+    if (!x) return AMT_OK;
+    DeviceScope scope(x->device);
+    if (x->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);
+    if (x->red) (void)hipFree(x->red);
+    for (void *q : x->opened) (void)hipIpcCloseMemHandle(q);
+    if (x->shm_registered) (void)hipHostUnregister(x->shm);
+    if (x->shm) (void)munmap(x->shm, x->shm_bytes);
+    delete x;
+    return AMT_OK;
+}
+
+int amt_exchange_create(AmtExchange **out, int transport, int rank, int world, const void *unique_id, int device,
+                        const AmtSeg *sends, int nsend, const AmtSeg *recvs, int nrecv, bool self_loop)
+{
+    *out = nullptr;
+    if (transport != AMT_XCHG_RCCL && transport != AMT_XCHG_IPC) return amt_fail(AMT_ERR_INVALID_ARG, "unknown halo transport %d", transport);
+    AmtExchange *x = new (std::nothrow) AmtExchange;
+    if (!x) return amt_fail(AMT_ERR_ALLOC, "host allocation failed");
+    x->transport = transport; x->rank = rank; x->world = world; x->device = device; x->self_loop = self_loop;
+    x->sends.assign(sends, sends + nsend);
+    x->recvs.assign(recvs, recvs + nrecv);
+    const bool needed = world > 1 || self_loop;
+    if (!needed) { *out = x; return AMT_OK; }
+    if (!unique_id) { delete x; return amt_fail(AMT_ERR_INVALID_ARG, "a communicator needs the unique id"); }
+    DeviceScope scope(device);
+    int rc = AMT_OK;
+    if (transport == AMT_XCHG_RCCL) {
+        rc = amt_rccl_load();
+        if (rc == AMT_OK && !memcmp(unique_id, kLocalIdMagic, 8))
+            rc = amt_fail(AMT_ERR_COMM, "this communicator id was made without RCCL (AMT_SLAB_TRANSPORT=ipc, or librccl was not found): "
+                                        "it serves the IPC transport only");
+        if (rc == AMT_OK && hipMalloc((void **)&x->red, sizeof(double)) != hipSuccess) rc = amt_fail(AMT_ERR_ALLOC, "device allocation failed");
+        if (rc == AMT_OK) {
+            ncclUniqueId id;
+            memcpy(&id, unique_id, sizeof id);
+            ncclResult_t r = g_rccl.CommInitRank(&x->comm, world, id, rank);
+            if (r != ncclSuccess) {
+                x->comm = nullptr;
+                rc = amt_fail(AMT_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+            }
+        }
+    } else {
+        rc = amt_ipc_setup(x, unique_id);
+    }
+    if (rc != AMT_OK) {
+        const std::string keep = amt_last_error();       // destroy must not lose the diagnosis
+        amt_exchange_destroy(x);
+        return amt_fail(rc, "%s", keep.c_str());
+    }
+    *out = x;
+    return AMT_OK;
+}
+
+bool amt_exchange_active(const AmtExchange *x) { return x && (!x->sends.empty() || !x->recvs.empty()) && (x->comm || x->shm); }
+int amt_exchange_transport(const AmtExchange *x) { return x ? x->transport : AMT_XCHG_RCCL; }
+void amt_exchange_bytes(const AmtExchange *x, size_t *sent, size_t *received)
+{
+    *sent = *received = 0;
+    if (!x) return;
+    for (const AmtSeg &s : x->sends) *sent += s.bytes;
+    for (const AmtSeg &s : x->recvs) *received += s.bytes;
+}
+
+int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream)
+{
+    if (!amt_exchange_active(x)) return AMT_OK;
+    if (x->transport == AMT_XCHG_RCCL) return amt_rccl_exchange(x, stream);
+    const unsigned long long n = ++x->seq;
+    ShmRank *me = x->slot(x->rank);
+    AmtDevPtrs src{};
+    for (int p : x->sources) src.p[src.n++] = x->dev(&x->slot(p)->ready);
+    hipLaunchKernelGGL(amt_xchg_post_and_wait, dim3(1), dim3(64), 0, stream, x->dev(&me->ready), src, n, x->ticks, x->dev(&me->error));
+    if (x->pull_kernel && !x->recvs.empty()) {
+        AmtPullSegs g{};
+        for (size_t r = 0; r < x->recvs.size(); ++r) { g.src[r] = x->recv_src[r]; g.dst[r] = x->recvs[r].ptr; g.bytes[r] = x->recvs[r].bytes; }
+        hipLaunchKernelGGL(amt_xchg_pull, dim3(8, (unsigned)x->recvs.size()), dim3(256), 0, stream, g);
+    } else {
+        for (size_t r = 0; r < x->recvs.size(); ++r)
+            AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    AmtDevPtrs done{};
+    for (int p : x->sources) done.p[done.n++] = x->dev(&x->slot(p)->pulled[x->rank]);
+    if (done.n) hipLaunchKernelGGL(amt_xchg_post, dim3(1), dim3(64), 0, stream, done, n);
+    AMT_HIP(hipGetLastError());
+    return AMT_OK;
+}
+
+int amt_exchange_enqueue_release(AmtExchange *x, hipStream_t stream)
+{
+    if (!amt_exchange_active(x) || x->transport != AMT_XCHG_IPC || x->released == x->seq) return AMT_OK;
+    ShmRank *me = x->slot(x->rank);
+    AmtDevPtrs w{};
+    for (int p : x->dests) w.p[w.n++] = x->dev(&me->pulled[p]);
+    if (w.n) hipLaunchKernelGGL(amt_xchg_wait, dim3(1), dim3(64), 0, stream, w, x->seq, x->ticks, x->dev(&me->error));
+    x->released = x->seq;
+    AMT_HIP(hipGetLastError());
+    return AMT_OK;
+}
+
+int amt_exchange_check(AmtExchange *x)
+{
+    if (!x || !x->shm) return AMT_OK;
+    const unsigned int e = __atomic_load_n(&x->slot(x->rank)->error, __ATOMIC_ACQUIRE);
+    if (e)
+        return amt_fail(AMT_ERR_COMM, "IPC halo exchange: a neighbour of rank %d did not %s within %.0f s (AMT_IPC_DEVICE_TIMEOUT_S); the halo "
+                                      "rows of that sweep are not valid", x->rank, e == 1 ? "post its rows" : "pull this rank's rows", x->ticks / 1e8);
+    return AMT_OK;
+}
+
+int amt_exchange_info(const AmtExchange *x, int *rank, int *world)
+{
+    int r = 0, w = 1;
+    if (x && x->comm) {
+        AMT_NCCL(g_rccl.CommUserRank(x->comm, &r));
+        AMT_NCCL(g_rccl.CommCount(x->comm, &w));
+    } else if (x && x->shm) {
+        r = x->rank;
+        w = (int)x->hdr()->attached.load();
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
+    return AMT_OK;
+}
+
+int amt_exchange_max(AmtExchange *x, double *v, hipStream_t stream)
+{
+    if (!x || x->world == 1) return AMT_OK;
+    if (x->comm) {
+        AMT_HIP(hipMemcpyAsync(x->red, v, sizeof(double), hipMemcpyHostToDevice, stream));
+        AMT_NCCL(g_rccl.AllReduce(x->red, x->red, 1, ncclDouble, ncclMax, x->comm, stream));
+        AMT_HIP(hipMemcpyAsync(v, x->red, sizeof(double), hipMemcpyDeviceToHost, stream));
+        AMT_HIP(hipStreamSynchronize(stream));
+        return AMT_OK;
+    }
+    if (!x->shm) return AMT_OK;
+    x->slot(x->rank)->red = *v;
+    int rc = amt_ipc_barrier(x);
+    if (rc) return rc;
+    double m = *v;
+    for (int r = 0; r < x->world; ++r) m = x->slot(r)->red > m ? x->slot(r)->red : m;
+    rc = amt_ipc_barrier(x);                         // nobody overwrites its value before all have read it
+    *v = m;
+    return rc;
+}

@@ -91,6 +91,7 @@ SYMBOLS = {
     "amt_slab_step": (_I, [_P, _I]),
     "amt_slab_step_timed": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
     "amt_slab_sync": (_I, [_P]),
+    "amt_slab_transport": (ctypes.c_char_p, [_P]),
     "amt_slab_set_skew_us": (_I, [_P, _I]),
     "amt_slab_halo_bytes": (_L, [_P]),
     "amt_slab_comm_info": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]),

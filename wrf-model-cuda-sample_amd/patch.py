@@ -277,13 +277,15 @@ class NativeSlabStepper:
     ``patch`` holds torch CUDA tensors (they stay the owners: ``amt_domain_wrap``); ``stream`` is
     the torch stream the sweeps are enqueued on; ``unique_id`` are the AMT_UNIQUE_ID_BYTES every rank
     got from rank 0's ``comm_unique_id()`` (None when world == 1 and not loopback).
-    Creating it is collective over the ``world`` ranks (ncclCommInitRank).
+    ``transport``: "rccl" (ncclSend/ncclRecv), or "ipc" (peer copies between the processes of one node through
+    hipIpcMemHandles and a shared-memory mailbox: no RCCL, ranks may share one device).
+    Creating it is collective over the ``world`` ranks (ncclCommInitRank / the IPC set-up).
     """
 
-    NO_OVERLAP, LOOPBACK = 1, 2          # enum amt_slab_flags
+    NO_OVERLAP, LOOPBACK, TRANSPORT_IPC = 1, 2, 4          # enum amt_slab_flags
 
     def __init__(self, patch: Patch, rank: int, world: int, unique_id: Optional[bytes] = None, *,
-                 stream=None, overlap: bool = True, variant: int = 0, loopback: bool = False):
+                 stream=None, overlap: bool = True, variant: int = 0, loopback: bool = False, transport: str = "rccl"):
         import ctypes
         import torch
         from . import lib as _lib
@@ -311,7 +313,10 @@ class NativeSlabStepper:
             try:
                 _lib.check(L.amt_domain_set_scalars(self._dom, patch.rdx, patch.rdy, patch.dts, patch.epssm))
                 _lib.check(L.amt_domain_set_variant(self._dom, int(variant)))
-                flags = (0 if overlap else self.NO_OVERLAP) | (self.LOOPBACK if loopback else 0)
+                if transport not in ("rccl", "ipc"):
+                    raise ValueError("transport is 'rccl' or 'ipc'")
+                flags = ((0 if overlap else self.NO_OVERLAP) | (self.LOOPBACK if loopback else 0)
+                         | (self.TRANSPORT_IPC if transport == "ipc" else 0))
                 uid = None
                 if unique_id is not None:
                     uid = (ctypes.c_char * 128).from_buffer_copy(bytes(unique_id))
@@ -351,10 +356,14 @@ class NativeSlabStepper:
         self._lib.check(self.L.amt_slab_set_skew_us(self._slab, int(microseconds)))
 
     def halo_bytes_per_sweep(self) -> int:
-        return 2 * int(self.L.amt_slab_halo_bytes(self._slab))       # sent + received
+        return int(self.L.amt_slab_halo_bytes(self._slab))           # sent + received
+
+    def transport(self) -> str:
+        """'rccl', 'ipc' or 'none' -- what carries this stepper's halo rows (amt_slab_transport)."""
+        return self.L.amt_slab_transport(self._slab).decode()
 
     def comm_info(self):
-        """(rank, world) as the RCCL communicator reports them; (0, 1) without one."""
+        """(rank, world) as the transport reports them (communicator / ranks attached to the IPC block); (0, 1) without one."""
         r, w = self._ct.c_int(), self._ct.c_int()
         self._lib.check(self.L.amt_slab_comm_info(self._slab, self._ct.byref(r), self._ct.byref(w)))
         return r.value, w.value
