@@ -293,3 +293,63 @@ def test_another_patch_or_a_release_never_drops_what_only_the_device_holds(pkg, 
     finally:
         pkg.host_defer(None, False)
         pkg.load_library().amt_host_release()
+
+
+def test_deferred_arrays_dropped_by_the_caller_are_kept_alive_until_flushed(pkg, oracle):
+    """host_defer(None); advance_mu_t(A...); del A; advance_mu_t(B...) -- the second call flushes A's deferred
+    outputs through A's ADDRESSES.  The Python binding holds A until then (api.held_arrays), so the flush writes into live
+    memory; B then comes out with the oracle's bits."""
+    import gc
+    import weakref
+    b = pkg.synth.domain_bounds(64, 10, 12)
+    pkg.host_defer(None, True)
+    try:
+        a = pkg.synth.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=1)
+        a_want = a.copy()
+        oracle.advance_mu_t(*a_want.args())
+        pkg.advance_mu_t(*a.args())
+        assert pkg.host_stale(None)
+        t_ref = weakref.ref(a.arrays["t"])
+        t_alias = a.arrays["t"]                                      # to read what the flush wrote (the binding's hold is what is tested)
+        held = pkg.held_arrays()
+        assert any(x is a.arrays["t"] for x in held) and len(held) == 26
+        del a, held
+        gc.collect()
+        assert t_ref() is not None                                   # alive: the binding holds it
+        b2 = pkg.synth.domain_bounds(48, 8, 10)                      # other extents: the library flushes A, then starts over
+        bb = pkg.synth.make_patch(b2, pkg.GridConfig(specified=True), dtype=np.float64, seed=2)
+        bb_want = bb.copy()
+        oracle.advance_mu_t(*bb_want.args())
+        pkg.advance_mu_t(*bb.args())
+        assert np.array_equal(t_alias.view(np.uint8), a_want.arrays["t"].view(np.uint8))    # A's t came down during B's call
+        pkg.host_fetch(None)
+        assert_patch_equal(pkg, bb, bb_want, "second set of arrays after the first was dropped")
+    finally:
+        pkg.host_defer(None, False)
+        pkg.host_release()
+    assert pkg.held_arrays() == ()
+
+
+def test_deferred_outputs_survive_a_change_of_device(pkg, oracle):
+    """the calling thread moves to another device between two calls; what only the first device holds must come
+    down to its host arrays before that device's workspace is given up."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    b = pkg.synth.domain_bounds(64, 10, 12)
+    pkg.host_defer(None, True)
+    try:
+        torch.cuda.set_device(0)
+        a = pkg.synth.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=1)
+        a_want = a.copy()
+        oracle.advance_mu_t(*a_want.args())
+        pkg.advance_mu_t(*a.args())
+        assert pkg.host_stale(None)
+        torch.cuda.set_device(1)
+        c = pkg.synth.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=3)
+        pkg.advance_mu_t(*c.args())
+        assert_patch_equal(pkg, a, a_want, "arrays of the first device after the thread moved on")
+    finally:
+        torch.cuda.set_device(0)
+        pkg.host_defer(None, False)
+        pkg.host_release()

@@ -14,6 +14,7 @@ Arrays are i-fastest: a 3-D field is a C-contiguous array of shape (jdim, kdim, 
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import numpy as np
 
@@ -132,13 +133,48 @@ def advance_mu_t(ww, ww_1, u, u_1, v, v_1, mu, mut, muave, muts, muu, muv, mudf,
             raise TypeError("host call needs contiguous numpy arrays of one dtype and of the memory extents")
     real = ctypes.c_float if dt == np.float32 else ctypes.c_double
     fn = L.amt_advance_mu_t_f32 if dt == np.float32 else L.amt_advance_mu_t_f64
-    status = fn(*[a.ctypes.data_as(ctypes.c_void_p) for a in arrays_a],
-                *[real(float(s)) for s in (rdx, rdy, dts, epssm)],
-                *[a.ctypes.data_as(ctypes.c_void_p) for a in arrays_b], *flags, *ints)
+    try:
+        status = fn(*[a.ctypes.data_as(ctypes.c_void_p) for a in arrays_a],
+                    *[real(float(s)) for s in (rdx, rdy, dts, epssm)],
+                    *[a.ctypes.data_as(ctypes.c_void_p) for a in arrays_b], *flags, *ints)
+    finally:
+        # the library may have flushed deferred outputs into the PREVIOUS call's arrays during this call (other arrays,
+        # other extents): those were kept alive until now; from here on it is this call's arrays it remembers
+        _remember(arrays_a + arrays_b)
     _lib.check(status)
 
 
 advance_mu_t.bind = bind_device_call        # SlabStepper pre-marshals its per-sweep launches through this
+
+
+# Lifetime of host arrays the library remembers.  With the residency cache or deferred outputs on, the library
+# keeps the host ADDRESSES of a call's arrays after the call returns: cached inputs are recognised by address, and a deferred
+# output is written through its address later (amt_host_fetch, the automatic flush on a key change / release / defer-off, the
+# check mode's canaries).  A C or Fortran host owns its arrays for the run; numpy arrays are garbage-collected -- so this
+# module holds strong references to the arrays of the calling thread's LAST one-shot call for as long as either mode is on in
+# that thread, and drops them when both are off and nothing is stale.
+_tl = threading.local()
+
+
+def _remember(arrays) -> None:
+    if getattr(_tl, "cache_on", False) or getattr(_tl, "defer_on", False) or _stale_any():
+        _tl.held = tuple(arrays)
+    else:
+        _tl.held = ()
+
+
+def _stale_any() -> bool:
+    return bool(_lib.load_library().amt_host_stale(None))
+
+
+def _forget_if_idle() -> None:
+    if not (getattr(_tl, "cache_on", False) or getattr(_tl, "defer_on", False)) and not _stale_any():
+        _tl.held = ()
+
+
+def held_arrays() -> tuple:
+    """The host arrays this module keeps alive for the calling thread (see above); () when none."""
+    return getattr(_tl, "held", ())
 
 
 def host_cache_enable(on: bool = True, check: bool = False) -> None:
@@ -147,14 +183,25 @@ def host_cache_enable(on: bool = True, check: bool = False) -> None:
     L = _lib.load_library()
     _lib.check(L.amt_host_cache_enable(int(bool(on))))
     _lib.check(L.amt_host_cache_check(int(bool(check))))
+    _tl.cache_on = bool(on)
+    _forget_if_idle()
 
 
 def host_defer(array=None, on: bool = True) -> None:
     """Deferred outputs of the one-shot (numpy) calls of the calling thread (header section 1: amt_host_defer): the
-    output ``array`` (None: all seven) stays on the device after a call until ``host_fetch``."""
+    output ``array`` (None: all seven) stays on the device after a call until ``host_fetch``.
+
+    Lifetime: the library writes the deferred values through the array's ADDRESS later (fetch, or the automatic flush when
+    another set of arrays, ``host_release`` or ``host_defer(..., False)`` comes).  This module keeps the arrays of the calling
+    thread's last call alive until then (``held_arrays``); arrays passed to the C-ABI directly must outlive that point."""
     L = _lib.load_library()
     ptr = None if array is None else array.ctypes.data_as(ctypes.c_void_p)
-    _lib.check(L.amt_host_defer(ptr, int(bool(on))))
+    _lib.check(L.amt_host_defer(ptr, int(bool(on))))        # defer-off fetches what is stale while the arrays are still held
+    if array is None:
+        _tl.defer_on = bool(on)
+    elif on:
+        _tl.defer_on = True
+    _forget_if_idle()
 
 
 def host_fetch(array=None) -> None:
@@ -162,6 +209,13 @@ def host_fetch(array=None) -> None:
     L = _lib.load_library()
     ptr = None if array is None else array.ctypes.data_as(ctypes.c_void_p)
     _lib.check(L.amt_host_fetch(ptr))
+    _forget_if_idle()
+
+
+def host_release() -> None:
+    """Free the calling thread's device workspace (amt_host_release): stale deferred outputs come down first."""
+    _lib.check(_lib.load_library().amt_host_release())
+    _forget_if_idle()
 
 
 def host_stale(array=None) -> bool:

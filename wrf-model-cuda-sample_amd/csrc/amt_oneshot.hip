@@ -460,6 +460,13 @@ static int amt_host_call(const AmtArgs<T> &h)
     // arena layout: [3-D inputs][3-D outputs][small outputs][small inputs] -- what comes down is
     // one contiguous range, and so is everything a packed call sends up
     HostWorkspace &ws = tl_workspace;
+    if (ws.device >= 0 && ws.device != device && ws.res.any_stale()) {
+        // the thread moved to another device: prepare() gives the old device's workspace up, and deferred outputs whose only
+        // current copy lives there must come down to their host arrays first (nothing the device alone holds is ever dropped,
+        // ADVICE r04) -- on the OLD device, whose streams still exist
+        rc = amt_keep_flush(ws);
+        if (rc != AMT_OK) return rc;
+    }
     {
         const hipError_t e = ws.prepare(device, big_bytes + small_bytes);
         if (e == hipErrorOutOfMemory) return amt_fail(AMT_ERR_ALLOC, "hipMalloc of %zu bytes failed", big_bytes + small_bytes);
