@@ -94,6 +94,11 @@ def parse():
                     help="N > 1, native stepper: what carries the halo rows -- rccl = ncclSend/ncclRecv (north_star's transport); "
                          "ipc = hipIpcMemHandles + a shared-memory mailbox + copy-engine pulls between the processes of one "
                          "node (no RCCL; no compute unit held while the wire is busy; ranks may share a device)")
+    ap.add_argument("--beside-rounds", type=int, default=0,
+                    help="N > 1: least rounds of workgroups of a slab's interior launch (amt_march_set_beside; 0 = library default 2)")
+    ap.add_argument("--beside-reserve", type=int, default=0,
+                    help="N > 1: compute units every round of the interior launch leaves free for the exchange and the edge rows "
+                         "(profiles/r05_slab_ab.md: 4 rounds / 16 units make the sweep flat in the neighbours' lateness)")
     ap.add_argument("--comm-timeout", type=float, default=120.0,
                     help="N > 1: most seconds a rank waits in the communicator set-up (ncclCommInitRank) and in the "
                          "first halo exchange before it ends itself with a diagnosis")
@@ -683,6 +688,8 @@ def run_rank(a):
 
     pkg = g.load_package()
     S = pkg.synth
+    if a.beside_rounds or a.beside_reserve:
+        pkg.load_library().amt_march_set_beside(a.beside_rounds, a.beside_reserve)
     dtype = np.float64 if a.dtype == "f64" else np.float32
     itemsize = np.dtype(dtype).itemsize
     dims = (a.ni, a.nk, a.nj)
@@ -932,6 +939,8 @@ def run_rank(a):
                        "halo_transport": ((stepper.transport() if native else "rccl") if a.backend == "nccl"
                                           else "gloo-host-staged (bring-up)") if world > 1 else None,
                        "ranks_share_a_device": bool(world > 1 and world > ndev),
+                       "halo_pull": (stepper.pull_mode() or None) if native else None,
+                       "interior_plan": {"beside_rounds": a.beside_rounds or 2, "beside_reserve_cus": a.beside_reserve} if world > 1 else None,
                        "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep(),
                        "placement_probe_ms": probe_ms,
                        "kernel": pkg.load_library().amt_march_last_kernel().decode()},

@@ -173,7 +173,10 @@ int amt_host_invalidate(const void *host_ptr);
  * alone holds is ever dropped by the library; a thread that ENDS without amt_host_release() loses it).
  * In the debug mode (amt_host_cache_check(1)) the window's cells of a deferred host array are overwritten with NaN
  * canaries after every call, so that a consumer reading the stale array computes NaNs instead of silently using old
- * values, and a call that finds them changed without an invalidate fails with AMT_ERR_PRECONDITION. */
+ * values, and a call that finds them changed without an invalidate fails with AMT_ERR_PRECONDITION.
+ * After a call that FAILS once its kernels were enqueued, the device copies of the deferred outputs are undefined (t, mu and
+ * level 1 of ww are advanced in place, chunk by chunk): amt_host_stale then returns -1 for them, amt_host_fetch and the next
+ * call fail with AMT_ERR_PRECONDITION, and amt_host_invalidate(ptr) -- the host array as last fetched is the truth -- clears it. */
 int amt_host_defer(const void *host_ptr, int on);
 int amt_host_fetch(const void *host_ptr);
 int amt_host_stale(const void *host_ptr);
@@ -320,7 +323,8 @@ int amt_synth_fill_device(void *hip_stream, int field, int dtype_bytes, void *ds
  *     the wire is busy -- RCCL's send/recv kernel holds 31) and posts "pulled"; a rank's sweep ends when its neighbours have
  *     pulled its rows.  The ranks must be processes of one node; they may share ONE device (how the two-rank tests run on
  *     a one-GPU box).  The arrays must come from hipMalloc or a pooled allocator over it (not hipMemMap ranges).
- *     AMT_IPC_PULL=kernel pulls with one kernel launch instead of six copy-engine transfers; AMT_IPC_TIMEOUT_S (120) bounds
+ *     AMT_IPC_PULL=engine|kernel overrides how the rows are pulled (amt_slab_pull_mode; AMT_IPC_PULL_WGS: workgroups of the
+ *     fused kernel, 4); AMT_IPC_TIMEOUT_S (120) bounds
  *     the host-side waits of the set-up, AMT_IPC_DEVICE_TIMEOUT_S (30) a device-side wait for a neighbour: it gives up,
  *     the sweep completes with invalid halo rows and amt_slab_sync returns AMT_ERR_COMM (nothing ever hangs the GPU).
  * ------------------------------------------------------------------------ */
@@ -355,9 +359,13 @@ int amt_slab_step(amt_slab *slab, int n_sweeps);             /* asynchronous    
 int amt_slab_step_timed(amt_slab *slab, int n_sweeps, float *ms_total);
 int amt_slab_sync(amt_slab *slab);               /* AMT_ERR_COMM if a device-side wait for a neighbour gave up (IPC) */
 const char *amt_slab_transport(const amt_slab *slab);        /* "rccl", "ipc", or "none" (a world of one)  */
+/* how the IPC transport pulls: "copy engine" (between GPUs: hipMemcpyAsync per row) or "fused kernel" (ranks that share a device,
+ * loopback: one kernel waits, pulls and posts -- a peer copy is a blit kernel there anyway); "" with RCCL */
+const char *amt_slab_pull_mode(const amt_slab *slab);
 /* Test hook: from now on every sweep's exchange starts `microseconds` late on the communication stream (a device-side
  * delay in front of the ncclSend/ncclRecv group), i.e. the neighbours' rows arrive that much late -- neighbour skew on
- * one GPU with the rank as its own neighbour (AMT_SLAB_LOOPBACK; profiles/slab_loopback.py --skew-us).  0 = off.
+ * one GPU with the rank as its own neighbour (AMT_SLAB_LOOPBACK; profiles/slab_loopback.py --skew-us).  0 = off.  (The IPC
+ * transport carries the delay inside its own waiting kernel: what waits is what would wait for a late neighbour.)
  * AMT_SLAB_SKEW_WGS=n in the environment gives the delay n workgroups that each hold a compute unit (31: what RCCL's
  * waiting send/recv kernel holds; default 1). */
 int amt_slab_set_skew_us(amt_slab *slab, int microseconds);
@@ -406,6 +414,14 @@ int amt_march_rows_for(long ntile_i, int nj, int cus, long max_rows, int wbytes,
  * whole launch; n > 0: every 8 n consecutive workgroup numbers cover 8 n consecutive blocks, n per XCD.  Which is
  * faster depends on where the arrays lie (profiles/r04_rows.md): not a tuning default. */
 int amt_march_set_xchunk(int n);
+/* How a launch made BESIDE another stream's kernels is planned (AMT_LAUNCH_BESIDE_OTHERS; a j-slab's interior).  A march workgroup
+ * takes a compute unit whole (all its LDS and registers), so the other stream's kernels -- the halo exchange, the edge rows -- start
+ * only where a workgroup ends, and every unit they take pushes interior workgroups into one more round.  `rounds`: least number of
+ * rounds of workgroups (more, shorter rounds: more places to start, and a shorter extra round; half a row of prologue per block);
+ * `reserve_cus`: compute units every round is planned to leave free (the other stream's kernels then start at once and push
+ * nothing).  0, 0 = the defaults (AMT_MARCH_BESIDE_ROUNDS / AMT_MARCH_BESIDE_RESERVE in the environment, else 2 and 0).
+ * Measured: profiles/r05_slab_ab.md. */
+int amt_march_set_beside(int rounds, int reserve_cus);
 
 #ifdef __cplusplus
 }

@@ -26,8 +26,14 @@ ap.add_argument("--nj", type=int, default=512)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--sweeps", type=int, default=200)
 ap.add_argument("--skew-us", type=int, nargs="*", default=[])
+ap.add_argument("--transport", choices=("rccl", "ipc"), default="rccl",
+                help="ipc: the copy-engine / mailbox transport in loopback (no RCCL kernel; AMT_IPC_PULL=kernel for the one-launch pull)")
+ap.add_argument("--beside-rounds", type=int, default=0, help="least rounds of workgroups of the interior launch (amt_march_set_beside; 0 = default)")
+ap.add_argument("--beside-reserve", type=int, default=0, help="compute units every round of the interior launch leaves free")
 a = ap.parse_args()
 pkg = g.load_package()
+if a.beside_rounds or a.beside_reserve:
+    pkg.load_library().amt_march_set_beside(a.beside_rounds, a.beside_reserve)
 S = pkg.synth
 dtype = np.float64 if a.dtype == "f64" else np.float32
 gdims = (a.ni, a.nk, 3 * a.nj)
@@ -48,15 +54,15 @@ dev = S.make_patch(b, pkg.GridConfig(), dtype=dtype, seed=1, global_dims=gdims, 
 bare = pkg.bind_device_call(*dev.args())
 print(f"{a.ni}x{a.nk}x{a.nj} {a.dtype} slab, bare sweep (one launch): {timed(lambda n: [bare() for _ in range(n)], a.sweeps):.4f} ms")
 for overlap in (True, False):
-    st = pkg.patch.NativeSlabStepper(dev, 0, 1, pkg.patch.NativeSlabStepper.comm_unique_id(), loopback=True, overlap=overlap)
+    st = pkg.patch.NativeSlabStepper(dev, 0, 1, pkg.patch.NativeSlabStepper.comm_unique_id(), loopback=True, overlap=overlap, transport=a.transport)
     ms = timed(lambda n: (st.step(n), st.sync()), a.sweeps)
-    print(f"  native stepper, RCCL loopback, {'overlap (interior || exchange + edges)' if overlap else 'no overlap (exchange, interior, edges)'}: "
-          f"{ms:.4f} ms, halo bytes {st.halo_bytes_per_sweep()}")
+    print(f"  native stepper, {a.transport.upper()} loopback, {'overlap (interior || exchange + edges)' if overlap else 'no overlap (exchange, interior, edges)'}: "
+          f"{ms:.4f} ms, halo bytes {st.halo_bytes_per_sweep()}{', pull by ' + st.pull_mode() if st.pull_mode() else ''}, interior {pkg.load_library().amt_march_last_kernel().decode().split('>')[-1].strip()}")
     st.close()
 
 if a.skew_us:
     print("skew of the neighbours' rows (us) -> ms per sweep, overlap on / off")
-    steppers = {ov: pkg.patch.NativeSlabStepper(dev, 0, 1, pkg.patch.NativeSlabStepper.comm_unique_id(), loopback=True, overlap=ov)
+    steppers = {ov: pkg.patch.NativeSlabStepper(dev, 0, 1, pkg.patch.NativeSlabStepper.comm_unique_id(), loopback=True, overlap=ov, transport=a.transport)
                 for ov in (True, False)}
     for us in a.skew_us:
         row = []

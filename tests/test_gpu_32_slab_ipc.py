@@ -56,11 +56,15 @@ def _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, world, dims, dtype,
             assert bits_equal(got, want.arrays[n][sb.jts - gb.jms: sb.jte + 1 - gb.jms]), f"rank {r}: {n} differs from the unsplit oracle run"
 
 
-@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "no-overlap"])
-def test_two_processes_on_one_device_at_4096x60x64_per_rank(pkg, oracle, tmp_path, overlap):
+@pytest.mark.parametrize("overlap,pull", [(True, "kernel"), (False, "kernel"), (True, "engine")],
+                         ids=["overlap-fused-kernel", "no-overlap-fused-kernel", "overlap-copy-engine"])
+def test_two_processes_on_one_device_at_4096x60x64_per_rank(pkg, oracle, tmp_path, overlap, pull):
+    """pull: ranks that share a device pull with the fused kernel by default; "engine" forces the path GPUs of a node take
+    (one hipMemcpyAsync per row from the peer mapping)."""
     dims = (4096, 60, 128)
-    outs = _run_ranks(tmp_path, 2, dims, overlap=overlap)
+    outs = _run_ranks(tmp_path, 2, dims, overlap=overlap, extra_env={"AMT_IPC_PULL": pull})
     assert all("transport ipc, ranks seen 2" in o for o in outs), outs
+    assert all(("fused kernel" if pull == "kernel" else "copy engine") in o for o in outs), outs
     _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 2, dims, "f64", 2)
 
 
@@ -71,9 +75,10 @@ def test_three_processes_uneven_rows_specified_boundaries_fp32(pkg, oracle, tmp_
     _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 3, dims, "f32", 3, specified=True)
 
 
-def test_pull_by_one_kernel_instead_of_the_copy_engine(pkg, oracle, tmp_path):
-    dims = (515, 33, 40)                   # rows that are not a multiple of 16 bytes: the pull kernel's tail
-    _run_ranks(tmp_path, 2, dims, dtype="f32", extra_env={"AMT_IPC_PULL": "kernel"})
+@pytest.mark.parametrize("pull", ["kernel", "engine"])
+def test_rows_that_are_not_a_multiple_of_16_bytes(pkg, oracle, tmp_path, pull):
+    dims = (515, 33, 40)                   # 517-element fp32 rows: the fused kernel's byte tail
+    _run_ranks(tmp_path, 2, dims, dtype="f32", extra_env={"AMT_IPC_PULL": pull})
     _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 2, dims, "f32", 2)
 
 

@@ -58,7 +58,7 @@ def main():
         st.sync()                                   # raises AmtError(ERR_COMM) if a device-side wait gave up
         for n in S.OUTPUTS:
             np.save(Path(a.dir) / f"out_{a.rank}_{n}.npy", dev.arrays[n][1:-1].cpu().numpy())
-        print(f"rank {a.rank}/{a.world}: rows {sb.jts}..{sb.jte}, transport {st.transport()}, ranks seen {seen[1]}, "
+        print(f"rank {a.rank}/{a.world}: rows {sb.jts}..{sb.jte}, transport {st.transport()}, ranks seen {seen[1]}, pull by {st.pull_mode()}, "
               f"kernel {L.amt_march_last_kernel().decode()}", flush=True)
     finally:
         st.close()

@@ -164,7 +164,7 @@ def _remember(arrays) -> None:
 
 
 def _stale_any() -> bool:
-    return bool(_lib.load_library().amt_host_stale(None))
+    return int(_lib.load_library().amt_host_stale(None)) != 0        # stale, or undefined after a failed call: still remembered
 
 
 def _forget_if_idle() -> None:
@@ -219,10 +219,15 @@ def host_release() -> None:
 
 
 def host_stale(array=None) -> bool:
-    """Is the device copy of a deferred output (None: of any) newer than the host array?"""
+    """Is the device copy of a deferred output (None: of any) newer than the host array?  Raises AmtError when the device
+    copy is undefined because a call failed part-way (``host_invalidate`` makes the host array the truth again)."""
     L = _lib.load_library()
     ptr = None if array is None else array.ctypes.data_as(ctypes.c_void_p)
-    return bool(L.amt_host_stale(ptr))
+    v = int(L.amt_host_stale(ptr))
+    if v < 0:
+        raise _lib.AmtError(_lib.ERR_PRECONDITION, "the device copy of a deferred output is undefined since a call failed part-way; "
+                                                   "host_invalidate(array) makes the host array the truth again")
+    return v > 0
 
 
 def host_invalidate(array=None) -> None:

@@ -40,4 +40,7 @@ int amt_exchange_info(const AmtExchange *x, int *rank, int *world);
 int amt_exchange_max(AmtExchange *x, double *v, hipStream_t stream);
 int amt_exchange_transport(const AmtExchange *x);
 void amt_exchange_bytes(const AmtExchange *x, size_t *sent, size_t *received);      // per exchange, this rank
+void amt_exchange_set_skew_us(AmtExchange *x, int microseconds);    // test hook: phase A completes this late
+bool amt_exchange_owns_skew(const AmtExchange *x);
+const char *amt_exchange_pull_mode(const AmtExchange *x);             // "fused kernel" / "copy engine" / "" (RCCL)
 bool amt_exchange_active(const AmtExchange *x);       // false: no segment at all (a world of one without loopback)

@@ -26,6 +26,7 @@ struct AmtRccl {
     void *lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitRankConfig)(ncclComm_t *, int, ncclUniqueId, int, ncclConfig_t *) = nullptr;   // optional
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -64,6 +65,7 @@ int amt_rccl_load()
     r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) { dlclose(lib); return amt_fail(AMT_ERR_COMM, "librccl lacks a send/recv entry point"); }
+    r.CommInitRankConfig = reinterpret_cast<decltype(r.CommInitRankConfig)>(dlsym(lib, "ncclCommInitRankConfig"));
     g_rccl = r;
     return AMT_OK;
 }
@@ -359,16 +361,17 @@ struct AmtDevPtrs {
 
 // "my send segments are final for exchange n", then wait until every source's are.  One wave; lane l polls source l.
 __global__ void amt_xchg_post_and_wait(unsigned long long *mine, AmtDevPtrs src, unsigned long long n,
-                                       unsigned long long ticks, unsigned int *err)
+                                       unsigned long long ticks, unsigned long long skew_ticks, unsigned int *err)
 {
+    const unsigned long long t0 = wall_clock64();
     if (threadIdx.x == 0) __hip_atomic_store(mine, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)threadIdx.x < src.n) {
-        const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(src.p[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < n) {
             if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(4);
         }
     }
+    while (wall_clock64() - t0 < skew_ticks) __builtin_amdgcn_s_sleep(8);            // test hook: the neighbours' rows are this late
 }
 __global__ void amt_xchg_post(AmtDevPtrs dst, unsigned long long n)
 {
@@ -385,26 +388,54 @@ __global__ void amt_xchg_wait(AmtDevPtrs src, unsigned long long n, unsigned lon
     }
 }
 
-// The pull as ONE kernel instead of one copy-engine transfer per segment (AMT_IPC_PULL=kernel): blockIdx.y = segment,
-// 16 bytes per lane.  Between GPUs it needs compute units for as long as the wire takes -- what the copy engine avoids;
-// on ONE shared device it is the faster of the two (profiles/r05_ipc_probe.txt).
 typedef unsigned int amt_v4u __attribute__((ext_vector_type(4)));
 struct AmtPullSegs {
     const void *src[kMaxExports];
     void *dst[kMaxExports];
     unsigned long long bytes[kMaxExports];
 };
-__global__ __launch_bounds__(256) void amt_xchg_pull(AmtPullSegs g)
+// The whole of phase A as ONE kernel (the default between ranks that share a device; AMT_IPC_PULL=kernel elsewhere): a march
+// workgroup takes a compute unit whole, so beside a slab's interior every kernel of the communication stream starts only where
+// an interior workgroup ends -- a chain of wait, six copies and post would queue at one such place after the other
+// (profiles/r05_slab_ab.md).  This kernel is enqueued BEFORE the interior, holds its `gridDim.x` compute units from the start of
+// the sweep (RCCL's send/recv kernel holds 31), posts "rows final", waits for the sources, pulls every segment and posts "pulled".
+struct AmtFusedArgs {
+    unsigned long long *ready_mine;
+    AmtDevPtrs src_ready, pulled_dst;
+    unsigned long long n, ticks, skew_ticks;
+    unsigned int *err, *wg_done;
+    int nseg;
+    AmtPullSegs segs;
+};
+__global__ __launch_bounds__(512) void amt_xchg_fused(AmtFusedArgs a)
 {
-    const size_t n16 = g.bytes[blockIdx.y] / 16;
-    const amt_v4u *src = static_cast<const amt_v4u *>(g.src[blockIdx.y]);
-    amt_v4u *dst = static_cast<amt_v4u *>(g.dst[blockIdx.y]);
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n16; e += (size_t)gridDim.x * blockDim.x)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + e), dst + e);
-    // a tail that is not a multiple of 16 bytes (rows are multiples of the element size only)
-    const size_t tail0 = n16 * 16, tail = g.bytes[blockIdx.y] - tail0;
-    if (blockIdx.x == 0 && threadIdx.x < tail)
-        static_cast<unsigned char *>(g.dst[blockIdx.y])[tail0 + threadIdx.x] = static_cast<const unsigned char *>(g.src[blockIdx.y])[tail0 + threadIdx.x];
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) __hip_atomic_store(a.ready_mine, a.n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = wall_clock64();
+        for (int q = 0; q < a.src_ready.n; ++q)
+            while (__hip_atomic_load(a.src_ready.p[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.n) {
+                if (wall_clock64() - t0 > a.ticks) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        while (wall_clock64() - t0 < a.skew_ticks) __builtin_amdgcn_s_sleep(8);      // test hook: the neighbours' rows are this late
+    }
+    __syncthreads();
+    for (int g = 0; g < a.nseg; ++g) {
+        const size_t n16 = a.segs.bytes[g] / 16;
+        const amt_v4u *src = static_cast<const amt_v4u *>(a.segs.src[g]);
+        amt_v4u *dst = static_cast<amt_v4u *>(a.segs.dst[g]);
+        for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n16; e += (size_t)gridDim.x * blockDim.x)
+            __builtin_nontemporal_store(__builtin_nontemporal_load(src + e), dst + e);
+        const size_t tail0 = n16 * 16, tail = a.segs.bytes[g] - tail0;
+        if (blockIdx.x == 0 && threadIdx.x < tail)
+            static_cast<unsigned char *>(a.segs.dst[g])[tail0 + threadIdx.x] = static_cast<const unsigned char *>(a.segs.src[g])[tail0 + threadIdx.x];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(a.wg_done, 1u) == gridDim.x - 1) {              // the last workgroup to finish posts
+        *a.wg_done = 0;
+        for (int q = 0; q < a.pulled_dst.n; ++q) __hip_atomic_store(a.pulled_dst.p[q], a.n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 double amt_env_seconds(const char *name, double dflt)
@@ -437,7 +468,11 @@ struct AmtExchange {
     std::vector<int> sources, dests;         // distinct peer ranks
     unsigned long long seq = 0;              // exchanges enqueued so far
     unsigned long long released = 0;
-    bool pull_kernel = false;
+    bool pull_kernel = false;               // one fused kernel (wait + pull + post) instead of wait kernel, copy-engine pulls, post kernel
+    bool same_device_peers = true;          // every source rank computes on this rank's device (ranks that share a GPU; loopback)
+    int pull_wgs = 4;
+    unsigned int *wg_done = nullptr;        // device counter of the fused kernel
+    unsigned long long skew_ticks = 0;      // test hook (amt_exchange_set_skew_us)
     unsigned long long ticks = 0;
     double host_timeout = 120.0;
 
@@ -483,7 +518,7 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
         return amt_fail(AMT_ERR_INVALID_ARG, "more than %d neighbours", kMaxPeers);
     x->host_timeout = amt_env_seconds("AMT_IPC_TIMEOUT_S", 120.0);
     x->ticks = (unsigned long long)(amt_env_seconds("AMT_IPC_DEVICE_TIMEOUT_S", 30.0) * 1e8);     // 100 MHz wall clock
-    if (const char *e = getenv("AMT_IPC_PULL")) x->pull_kernel = !strcmp(e, "kernel");
+    if (const char *e = getenv("AMT_IPC_PULL_WGS")) { const int n = atoi(e); if (n >= 1 && n <= 64) x->pull_wgs = n; }
 
     // the block: one name per (unique id, how many exchanges this process made with it before) -- every rank creates
     // its exchanges in the same order, so the counters agree; whoever comes first creates it, rank 0 removes the name
@@ -588,6 +623,19 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
             x->recv_src[r] = static_cast<char *>(it->second) + e.offset;
         }
     }
+    // How the rows are pulled.  Between GPUs: the copy engine (SDMA over xGMI, no compute unit).  Between ranks that share a
+    // device -- and in loopback -- a peer "copy" is a blit kernel anyway (22 us each through the IPC mapping, profiles/
+    // r05_ipc_probe.txt): there one fused kernel does the whole phase.  AMT_IPC_PULL=engine|kernel overrides.
+    for (int p : x->sources)
+        if (strncmp(x->slot(p)->bus_id, me->bus_id, sizeof me->bus_id) != 0) x->same_device_peers = false;
+    x->pull_kernel = x->same_device_peers;
+    if (const char *e = getenv("AMT_IPC_PULL")) {
+        if (!strcmp(e, "kernel")) x->pull_kernel = true;
+        else if (!strcmp(e, "engine")) x->pull_kernel = false;
+        else if (*e) return amt_fail(AMT_ERR_INVALID_ARG, "AMT_IPC_PULL must be engine or kernel, not '%s'", e);
+    }
+    AMT_HIP(hipMalloc((void **)&x->wg_done, sizeof(unsigned int)));
+    AMT_HIP(hipMemset(x->wg_done, 0, sizeof(unsigned int)));
     // everybody attached: the name can go (the mappings stay)
     h->attached.fetch_add(1, std::memory_order_acq_rel);
     while (h->attached.load(std::memory_order_acquire) < (uint32_t)world) {
@@ -622,6 +670,7 @@ int amt_exchange_destroy(AmtExchange *x)
     DeviceScope scope(x->device);
     if (x->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);
     if (x->red) (void)hipFree(x->red);
+    if (x->wg_done) (void)hipFree(x->wg_done);
     for (void *q : x->opened) (void)hipIpcCloseMemHandle(q);
     if (x->shm_registered) (void)hipHostUnregister(x->shm);
     if (x->shm) (void)munmap(x->shm, x->shm_bytes);
@@ -653,7 +702,21 @@ int amt_exchange_create(AmtExchange **out, int transport, int rank, int world, c
         if (rc == AMT_OK) {
             ncclUniqueId id;
             memcpy(&id, unique_id, sizeof id);
-            ncclResult_t r = g_rccl.CommInitRank(&x->comm, world, id, rank);
+            // The send/recv kernel of a communicator runs one workgroup per channel and every one of them holds a compute unit
+            // for as long as the kernel waits for the wire: 31 by default, beside an interior launch whose workgroups need whole
+            // units (profiles/r05_slab_ab.md).  Six rows per neighbour do not need 31 channels: this communicator is capped at
+            // AMT_RCCL_MAX_CTAS (4; 0 = RCCL's own default).
+            int max_ctas = 4;
+            if (const char *e = getenv("AMT_RCCL_MAX_CTAS")) max_ctas = atoi(e);
+            ncclResult_t r;
+            if (max_ctas > 0 && g_rccl.CommInitRankConfig) {
+                ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+                cfg.maxCTAs = max_ctas;
+                cfg.minCTAs = 1;
+                r = g_rccl.CommInitRankConfig(&x->comm, world, id, rank, &cfg);
+            } else {
+                r = g_rccl.CommInitRank(&x->comm, world, id, rank);
+            }
             if (r != ncclSuccess) {
                 x->comm = nullptr;
                 rc = amt_fail(AMT_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
@@ -671,6 +734,14 @@ int amt_exchange_create(AmtExchange **out, int transport, int rank, int world, c
     return AMT_OK;
 }
 
+void amt_exchange_set_skew_us(AmtExchange *x, int microseconds) { if (x) x->skew_ticks = (unsigned long long)microseconds * 100ull; }
+// does the transport carry the test skew itself (IPC: inside its waiting kernel)?  RCCL: the stepper delays the stream
+bool amt_exchange_owns_skew(const AmtExchange *x) { return x && x->transport == AMT_XCHG_IPC && x->shm; }
+const char *amt_exchange_pull_mode(const AmtExchange *x)
+{
+    if (!x || x->transport != AMT_XCHG_IPC || !x->shm) return "";
+    return x->pull_kernel ? "fused kernel" : "copy engine";
+}
 bool amt_exchange_active(const AmtExchange *x) { return x && (!x->sends.empty() || !x->recvs.empty()) && (x->comm || x->shm); }
 int amt_exchange_transport(const AmtExchange *x) { return x ? x->transport : AMT_XCHG_RCCL; }
 void amt_exchange_bytes(const AmtExchange *x, size_t *sent, size_t *received)
@@ -687,19 +758,23 @@ int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream)
     if (x->transport == AMT_XCHG_RCCL) return amt_rccl_exchange(x, stream);
     const unsigned long long n = ++x->seq;
     ShmRank *me = x->slot(x->rank);
-    AmtDevPtrs src{};
+    AmtDevPtrs src{}, done{};
     for (int p : x->sources) src.p[src.n++] = x->dev(&x->slot(p)->ready);
-    hipLaunchKernelGGL(amt_xchg_post_and_wait, dim3(1), dim3(64), 0, stream, x->dev(&me->ready), src, n, x->ticks, x->dev(&me->error));
-    if (x->pull_kernel && !x->recvs.empty()) {
-        AmtPullSegs g{};
-        for (size_t r = 0; r < x->recvs.size(); ++r) { g.src[r] = x->recv_src[r]; g.dst[r] = x->recvs[r].ptr; g.bytes[r] = x->recvs[r].bytes; }
-        hipLaunchKernelGGL(amt_xchg_pull, dim3(8, (unsigned)x->recvs.size()), dim3(256), 0, stream, g);
-    } else {
-        for (size_t r = 0; r < x->recvs.size(); ++r)
-            AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, hipMemcpyDeviceToDevice, stream));
-    }
-    AmtDevPtrs done{};
     for (int p : x->sources) done.p[done.n++] = x->dev(&x->slot(p)->pulled[x->rank]);
+    if (x->pull_kernel) {
+        AmtFusedArgs a{};
+        a.ready_mine = x->dev(&me->ready); a.src_ready = src; a.pulled_dst = done;
+        a.n = n; a.ticks = x->ticks; a.skew_ticks = x->skew_ticks;
+        a.err = x->dev(&me->error); a.wg_done = x->wg_done;
+        a.nseg = (int)x->recvs.size();
+        for (size_t r = 0; r < x->recvs.size(); ++r) { a.segs.src[r] = x->recv_src[r]; a.segs.dst[r] = x->recvs[r].ptr; a.segs.bytes[r] = x->recvs[r].bytes; }
+        hipLaunchKernelGGL(amt_xchg_fused, dim3((unsigned)x->pull_wgs), dim3(512), 0, stream, a);
+        AMT_HIP(hipGetLastError());
+        return AMT_OK;
+    }
+    hipLaunchKernelGGL(amt_xchg_post_and_wait, dim3(1), dim3(64), 0, stream, x->dev(&me->ready), src, n, x->ticks, x->skew_ticks, x->dev(&me->error));
+    for (size_t r = 0; r < x->recvs.size(); ++r)
+        AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, hipMemcpyDeviceToDevice, stream));
     if (done.n) hipLaunchKernelGGL(amt_xchg_post, dim3(1), dim3(64), 0, stream, done, n);
     AMT_HIP(hipGetLastError());
     return AMT_OK;

@@ -229,13 +229,20 @@ extern "C" int amt_domain_tune_placement(amt_domain *d, int tries, float *ms_per
     // what the timed sweeps overwrite, kept aside
     void *keep[AMT_F_COUNT] = {};
     auto free_set = [](void **set) { for (int f = 0; f < AMT_F_COUNT; ++f) if (set[f]) { (void)hipFree(set[f]); set[f] = nullptr; } };
+    hipError_t copy_err = hipSuccess;
+    auto note = [&](hipError_t e) { if (e != hipSuccess && copy_err == hipSuccess) copy_err = e; };
     for (int f : mutated) {
         if (hipMalloc(&keep[f], bytes(f)) != hipSuccess) {
             (void)hipGetLastError();
             free_set(keep);
             return amt_fail(AMT_ERR_ALLOC, "amt_domain_tune_placement: no room for a copy of the output arrays (nothing changed)");
         }
-        AMT_HIP(hipMemcpyAsync(keep[f], d->field[f], bytes(f), hipMemcpyDeviceToDevice, d->stream));
+        note(hipMemcpyAsync(keep[f], d->field[f], bytes(f), hipMemcpyDeviceToDevice, d->stream));
+    }
+    note(hipStreamSynchronize(d->stream));
+    if (copy_err != hipSuccess) {                                 // nothing was changed yet
+        free_set(keep);
+        return amt_fail(AMT_ERR_HIP, "amt_domain_tune_placement: saving the output arrays failed: %s", hipGetErrorString(copy_err));
     }
     float best = 0.f;
     int rc = time_current(&best);
@@ -252,9 +259,16 @@ extern "C" int amt_domain_tune_placement(amt_domain *d, int tries, float *ms_per
             free_set(cand);
             break;
         }
-        for (int f = 0; f < AMT_F_COUNT; ++f) {
+        hipError_t ce = hipSuccess;
+        for (int f = 0; f < AMT_F_COUNT && ce == hipSuccess; ++f) {
             const bool mut = keep[f] != nullptr;
-            (void)hipMemcpyAsync(cand[f], mut ? keep[f] : d->field[f], bytes(f), hipMemcpyDeviceToDevice, d->stream);
+            ce = hipMemcpyAsync(cand[f], mut ? keep[f] : d->field[f], bytes(f), hipMemcpyDeviceToDevice, d->stream);
+        }
+        if (ce == hipSuccess) ce = hipStreamSynchronize(d->stream);
+        if (ce != hipSuccess) {                                   // a candidate with unknown contents is neither timed nor kept
+            (void)hipGetLastError();
+            free_set(cand);
+            continue;
         }
         void *cur[AMT_F_COUNT];
         memcpy(cur, d->field, sizeof cur);
@@ -271,9 +285,11 @@ extern "C" int amt_domain_tune_placement(amt_domain *d, int tries, float *ms_per
         }
     }
     for (int f : mutated)                                         // contents as they were before the call
-        (void)hipMemcpyAsync(d->field[f], keep[f], bytes(f), hipMemcpyDeviceToDevice, d->stream);
-    (void)hipStreamSynchronize(d->stream);
+        note(hipMemcpyAsync(d->field[f], keep[f], bytes(f), hipMemcpyDeviceToDevice, d->stream));
+    note(hipStreamSynchronize(d->stream));
     free_set(keep);
+    if (copy_err != hipSuccess)
+        return amt_fail(AMT_ERR_HIP, "amt_domain_tune_placement: restoring the output arrays failed: %s (their contents are undefined)", hipGetErrorString(copy_err));
     return rc;
 }
 

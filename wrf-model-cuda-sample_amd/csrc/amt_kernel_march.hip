@@ -547,8 +547,8 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
 
         // Wave-uniform base pointers (SGPR pairs), fixed for the whole march: element (column 0 of
         // the tile, the wave's first level, row ja) of every 3-D array.  The column, the level group,
-        // the level step and the row advance go into a 32-bit per-lane byte offset, which the
-        // launcher keeps below 2^31.
+        // the level step and the row advance go into an UNSIGNED 32-bit per-lane byte offset, which the
+        // launcher keeps below 2^32 (amt_march_rows_for: max_rows).
         const long e3 = (long)ja * js + (long)(p.k1 + kfw) * idim + (long)col0;
         const T *u_b = p.u + e3, *u1_b = p.u_1 + e3, *ft_b = p.ft + e3, *ww1_b = p.ww_1 + e3;
         const T *t1_b = p.t_1 + e3, *v_b = p.v + e3, *v1_b = p.v_1 + e3;   // row ja
@@ -1053,8 +1053,10 @@ template <typename T> static AmtMarchEntry<T> *amt_march_find(const AmtMarchShap
 // that walk every instantiation; 0 / -1 leave a parameter to the launcher.
 struct AmtMarchEnv {
     int dma, kpt, hl, vw, xd, jrows, verbose, wm, xchunk;
+    int beside_rounds;     // least rounds of workgroups of a launch beside another stream's kernels (AmtParams::edges == 2)
+    int beside_reserve;    // compute units such a launch is planned to leave free in every round
 };
-static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 0};
+static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 0, 2, 0};
 // The instantiation the last plan of the calling thread chose (diagnosis / tests): "" before any launch.
 static thread_local char g_march_last[360] = "";
 extern "C" const char *amt_march_last_kernel(void) { return g_march_last; }
@@ -1068,7 +1070,10 @@ static const AmtMarchEnv &amt_march_env()
                        amt_env_int("AMT_MARCH_HL", 0), amt_env_int("AMT_MARCH_VW", 0),
                        amt_env_int("AMT_MARCH_XD", -1), amt_env_int("AMT_MARCH_JROWS", 0),
                        amt_env_int("AMT_MARCH_VERBOSE", 0), amt_env_int("AMT_MARCH_WM", 0),
-                       amt_env_int("AMT_MARCH_XCHUNK", 0)};
+                       amt_env_int("AMT_MARCH_XCHUNK", 0), amt_env_int("AMT_MARCH_BESIDE_ROUNDS", 2),
+                       amt_env_int("AMT_MARCH_BESIDE_RESERVE", 0)};
+        if (g_march_env.beside_rounds < 1) g_march_env.beside_rounds = 1;
+        if (g_march_env.beside_reserve < 0) g_march_env.beside_reserve = 0;
     });
     return g_march_env;
 }
@@ -1085,6 +1090,23 @@ extern "C" int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, i
     g_march_env.wm = wm > 0 ? wm : 0;
     ++g_march_generation;
     return 0;
+}
+
+extern "C" int amt_march_set_beside(int rounds, int reserve_cus)
+{
+    (void)amt_march_env();
+    g_march_env.beside_rounds = rounds > 0 ? rounds : 2;
+    g_march_env.beside_reserve = reserve_cus > 0 ? reserve_cus : 0;
+    ++g_march_generation;
+    return 0;
+}
+
+// compute units a launch is planned for: all of them, or -- beside another stream's kernels -- all but the reserve
+static int amt_march_plan_cus(int cus, int edges)
+{
+    if (edges != 2) return cus;
+    const int left = cus - amt_march_env().beside_reserve;
+    return left > cus / 2 ? left : cus / 2 > 0 ? cus / 2 : 1;
 }
 
 extern "C" int amt_march_set_xchunk(int xchunk)
@@ -1237,7 +1259,7 @@ template <typename T> static bool amt_march_pick(const AmtParams<T> &p, AmtMarch
                 const int tc = (64 / q.hl) * q.vw;
                 double c = 0;
                 long rounds = 1;
-                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, cus, amt_march_max_rows(p), amt_march_rows_cap((int)sizeof(T), q.hl), p.edges == 2 ? 2 : 1, &c, &rounds);
+                amt_march_rows((p.i1 - amt_march_col_lo(p)) / tc + 1, nj, amt_march_plan_cus(cus, p.edges), amt_march_max_rows(p), amt_march_rows_cap((int)sizeof(T), q.hl), p.edges == 2 ? amt_march_env().beside_rounds : 1, &c, &rounds);
                 return c * (q.hl == out.hl ? 1.0 : rounds == 1 ? 0.8 : 1.2);
             };
             if (out.hl < 4)
@@ -1304,7 +1326,7 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
     g.col_lo = amt_march_col_lo(p);
     g.ntile_i = (p.i1 - g.col_lo) / tc + 1;
     int jrows = env.jrows;
-    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_cus(pl.dev), max_rows, amt_march_rows_cap((int)sizeof(T), s.hl), p.edges == 2 ? 2 : 1, nullptr, nullptr);
+    if (jrows < 1) jrows = amt_march_rows(g.ntile_i, nj, amt_march_plan_cus(amt_march_cus(pl.dev), p.edges), max_rows, amt_march_rows_cap((int)sizeof(T), s.hl), p.edges == 2 ? amt_march_env().beside_rounds : 1, nullptr, nullptr);
     if (jrows > nj) jrows = nj;
     if (jrows > max_rows) jrows = (int)max_rows;
     g.jrows = jrows;

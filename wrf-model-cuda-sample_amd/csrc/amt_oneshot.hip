@@ -51,6 +51,7 @@ struct HostWorkspace {
         bool active[NKEEP] = {};                              // kept by the calls of the current key
         bool valid[NKEEP] = {};                               // the device copy is current
         bool stale[NKEEP] = {};                               // deferred: the device copy is NEWER than the host array
+        bool poisoned[NKEEP] = {};                            // deferred in/out: a FAILED call may have advanced part of the device copy
         uint64_t sum[NKEEP] = {};                             // check mode: checksum of what was uploaded / of the canary
         const void *host[NKEEP] = {};
         int key[16] = {};                                     // element size, extents, window, device
@@ -74,7 +75,7 @@ struct HostWorkspace {
         {
             for (int r = 0; r < NKEEP; ++r) {
                 if (buf[r]) (void)hipFree(buf[r]);
-                buf[r] = nullptr; bytes[r] = 0; active[r] = valid[r] = stale[r] = false; host[r] = nullptr; sum[r] = 0;
+                buf[r] = nullptr; bytes[r] = 0; active[r] = valid[r] = stale[r] = poisoned[r] = false; host[r] = nullptr; sum[r] = 0;
             }
         }
     } res;
@@ -296,7 +297,7 @@ extern "C" int amt_host_invalidate(const void *host_ptr)
     // is the truth again (whatever the device still held for it is given up)
     HostWorkspace::Kept &r = tl_workspace.res;
     for (int q = 0; q < HostWorkspace::NKEEP; ++q)
-        if (!host_ptr || r.host[q] == host_ptr) { r.valid[q] = false; r.stale[q] = false; }
+        if (!host_ptr || r.host[q] == host_ptr) { r.valid[q] = false; r.stale[q] = false; r.poisoned[q] = false; }
     return AMT_OK;                                            // an array that is not kept is uploaded anyway
 }
 
@@ -333,6 +334,10 @@ extern "C" int amt_host_fetch(const void *host_ptr)
     if (ws.device < 0) return AMT_OK;
     DeviceScope dev(ws.device);
     for (int r = HostWorkspace::NCACHE; r < HostWorkspace::NKEEP; ++r)
+        if ((!host_ptr || ws.res.host[r] == host_ptr) && ws.res.poisoned[r])
+            return amt_fail(AMT_ERR_PRECONDITION, "deferred output %s: its device copy is undefined since a call failed part-way (some rows may be "
+                            "a sub-step ahead); nothing is brought down -- amt_host_invalidate(ptr) makes the host array the truth again", kKeepName[r]);
+    for (int r = HostWorkspace::NCACHE; r < HostWorkspace::NKEEP; ++r)
         if (!host_ptr || ws.res.host[r] == host_ptr) AMT_HIP(amt_keep_fetch(ws, r));
     return AMT_OK;
 }
@@ -340,6 +345,8 @@ extern "C" int amt_host_fetch(const void *host_ptr)
 extern "C" int amt_host_stale(const void *host_ptr)
 {
     const HostWorkspace::Kept &k = tl_workspace.res;
+    for (int r = HostWorkspace::NCACHE; r < HostWorkspace::NKEEP; ++r)
+        if (k.poisoned[r] && (!host_ptr || k.host[r] == host_ptr)) return -1;      // undefined after a failed call
     for (int r = HostWorkspace::NCACHE; r < HostWorkspace::NKEEP; ++r)
         if (k.stale[r] && (!host_ptr || k.host[r] == host_ptr)) return 1;
     return 0;
@@ -542,6 +549,10 @@ static int amt_host_call(const AmtArgs<T> &h)
             if (!res.active[r]) continue;
             const int f = kKeepField[r];
             res_of[f] = r;
+            if (res.poisoned[r])
+                return amt_fail(AMT_ERR_PRECONDITION, "deferred output %s: an earlier call failed part-way and its device copy is undefined; "
+                                "call amt_host_invalidate for it (the host array, as last fetched, is the truth again) before the next sub-step",
+                                kKeepName[r]);
             res_upload[r] = !res.valid[r] && items[f].in;
             if (!res.check) continue;
             if (r < HostWorkspace::NCACHE) {
@@ -565,6 +576,19 @@ static int amt_host_call(const AmtArgs<T> &h)
             }
         }
     }
+    // A call that fails after its first kernel went out (any of the early returns below) leaves the deferred in/out copies
+    // (level 1 of ww, t, mu: advanced in place, chunk by chunk) partly a sub-step ahead: a retry would apply the sub-step twice
+    // to those rows and a fetch would bring a half-advanced state down.  They are marked undefined.
+    struct FailGuard {
+        HostWorkspace::Kept &k;
+        bool launched = false, ok = false;
+        ~FailGuard()
+        {
+            if (!launched || ok) return;
+            for (int r = HostWorkspace::NCACHE; r < HostWorkspace::NKEEP; ++r)
+                if (k.active[r] && (k.stale[r] || k.valid[r])) { k.valid[r] = k.stale[r] = false; k.poisoned[r] = true; }
+        }
+    } fail_guard{res};
     // staging buffer: mirrors the arena from stage_base on
     const size_t stage_base = pack_big ? 0 : small_begin;
     char *stage = nullptr;
@@ -735,7 +759,10 @@ static int amt_host_call(const AmtArgs<T> &h)
         d.msfvx_inv = q[23]; d.msftx = q[24]; d.msfty = q[25];
         d.jms = ja; d.jme = c1 + 1; d.jts = c0; d.jte = c1;  // a tile of the same domain (global jds, jde)
         AMT_HIP(hipStreamWaitEvent(comp, ws.uploaded[s], 0));
+        fail_guard.launched = true;
         rc = amt_device_call<T>(comp, AMT_VARIANT_AUTO, d);
+        if (rc == AMT_OK && getenv("AMT_TEST_FAIL_AFTER_LAUNCH"))   // test hook: a failure after the first kernel went out
+            rc = amt_fail(AMT_ERR_HIP, "AMT_TEST_FAIL_AFTER_LAUNCH: simulated failure after chunk %d was launched", c);
         if (rc != AMT_OK) break;
         AMT_HIP(hipEventRecord(ws.computed[s], comp));
         if (threaded) {
@@ -795,13 +822,14 @@ static int amt_host_call(const AmtArgs<T> &h)
         if (e != hipSuccess && rc == AMT_OK)
             rc = amt_fail(AMT_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
     }
+    fail_guard.ok = (rc == AMT_OK);
     for (int r = 0; r < HostWorkspace::NKEEP; ++r) {
         if (!res.active[r]) continue;
         if (r < HostWorkspace::NCACHE) {
             res.valid[r] = (rc == AMT_OK);                    // a cached input of a failed call simply goes up again
         } else if (rc == AMT_OK) {
-            // the device copy is the truth from here on.  (After a FAILED call the flags stay as they were: what the device
-            // held before the call is still what amt_host_fetch brings down, if the failure left it intact.)
+            // the device copy is the truth from here on.  (After a call that FAILED once kernels were out, fail_guard marks the
+            // deferred copies undefined: amt_host_fetch / the next call refuse them until amt_host_invalidate.)
             res.valid[r] = res.stale[r] = true;
             if (res.check) amt_keep_canary(res, r, true);
         }

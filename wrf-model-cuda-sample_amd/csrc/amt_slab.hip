@@ -154,13 +154,23 @@ int amt_slab_step_t(amt_slab *s, int n_sweeps)
         // rows that read a neighbour's data: jlo (slab below), jhi (slab above); the rest is interior
         const int in_lo = jlo + (lo ? 1 : 0), in_hi = jhi - (hi ? 1 : 0);
         hipStream_t edge_stream = s->overlap ? s->comm_stream : d->stream;
+        // Order of the enqueues (profiles/r05_slab_ab.md).  A march workgroup takes a compute unit whole, so whatever the
+        // communication stream launches once the interior is out starts only where an interior workgroup ends.  With the IPC
+        // transport the exchange therefore goes out FIRST: its waiting kernel has its compute unit(s) from the start of the
+        // sweep and the rows are in as soon as the neighbour has them.  RCCL's send/recv kernel would hold 31 units for as
+        // long as it waits, so there the interior keeps its head start (AMT_SLAB_EXCHANGE_FIRST=0|1 overrides either).
+        static const int order_env = [] { const char *e = getenv("AMT_SLAB_EXCHANGE_FIRST"); return e && *e ? atoi(e) : -1; }();
+        const bool exchange_first = order_env >= 0 ? order_env != 0 : amt_exchange_transport(s->xchg) == AMT_XCHG_IPC;
+        auto interior_beside = [&]() { return amt_slab_tile<T>(s, d->stream, in_lo, in_hi, true); };
         if (s->overlap) {
             AMT_HIP(hipEventRecord(s->inputs_final, d->stream));          // this sub-step's inputs are final
             AMT_HIP(hipStreamWaitEvent(s->comm_stream, s->inputs_final, 0));
-            rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi, true);        // interior overlaps the exchange
-            if (rc) { join(); return rc; }
+            if (!exchange_first) {
+                rc = interior_beside();                                    // interior overlaps the exchange
+                if (rc) { join(); return rc; }
+            }
         }
-        if (s->skew_us > 0) {
+        if (s->skew_us > 0 && !amt_exchange_owns_skew(s->xchg)) {
             static const int wgs = [] { const char *e = getenv("AMT_SLAB_SKEW_WGS"); const int n = e ? atoi(e) : 1; return n > 1 ? n : 1; }();
             if (wgs > 1) {
                 static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_slab_delay_kernel),
@@ -173,6 +183,10 @@ int amt_slab_step_t(amt_slab *s, int n_sweeps)
         }
         rc = amt_exchange_enqueue(s->xchg, edge_stream);
         if (rc) { join(); return rc; }
+        if (s->overlap && exchange_first) {
+            rc = interior_beside();
+            if (rc) { join(); return rc; }
+        }
         if (!s->overlap) {
             rc = amt_slab_tile<T>(s, d->stream, in_lo, in_hi);
             if (rc) return rc;
@@ -240,6 +254,7 @@ extern "C" int amt_slab_set_skew_us(amt_slab *s, int microseconds)
 {
     if (!s || microseconds < 0) return amt_fail(AMT_ERR_INVALID_ARG, "bad skew argument");
     s->skew_us = microseconds;
+    amt_exchange_set_skew_us(s->xchg, microseconds);      // the IPC transport carries it inside its waiting kernel
     return AMT_OK;
 }
 
@@ -257,6 +272,8 @@ extern "C" const char *amt_slab_transport(const amt_slab *s)
     if (!s || !amt_exchange_active(s->xchg)) return "none";
     return amt_exchange_transport(s->xchg) == AMT_XCHG_IPC ? "ipc" : "rccl";
 }
+
+extern "C" const char *amt_slab_pull_mode(const amt_slab *s) { return s ? amt_exchange_pull_mode(s->xchg) : ""; }
 
 extern "C" long amt_slab_halo_bytes(const amt_slab *s)
 {

@@ -92,6 +92,7 @@ SYMBOLS = {
     "amt_slab_step_timed": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
     "amt_slab_sync": (_I, [_P]),
     "amt_slab_transport": (ctypes.c_char_p, [_P]),
+    "amt_slab_pull_mode": (ctypes.c_char_p, [_P]),
     "amt_slab_set_skew_us": (_I, [_P, _I]),
     "amt_slab_halo_bytes": (_L, [_P]),
     "amt_slab_comm_info": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
@@ -100,6 +101,7 @@ SYMBOLS = {
     "amt_march_force_shape": (_I, [_I] * 7),
     "amt_march_rows_for": (_I, [ctypes.c_long, _I, _I, ctypes.c_long, _I, _I]),
     "amt_march_set_xchunk": (_I, [_I]),
+    "amt_march_set_beside": (_I, [_I, _I]),
     "amt_march_last_kernel": (ctypes.c_char_p, []),
     "amt_march_selectable": (_I, [ctypes.c_char_p, _I]),
 }

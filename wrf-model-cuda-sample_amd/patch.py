@@ -362,6 +362,10 @@ class NativeSlabStepper:
         """'rccl', 'ipc' or 'none' -- what carries this stepper's halo rows (amt_slab_transport)."""
         return self.L.amt_slab_transport(self._slab).decode()
 
+    def pull_mode(self) -> str:
+        """IPC transport: 'copy engine' or 'fused kernel' (amt_slab_pull_mode); '' with RCCL."""
+        return self.L.amt_slab_pull_mode(self._slab).decode()
+
     def comm_info(self):
         """(rank, world) as the transport reports them (communicator / ranks attached to the IPC block); (0, 1) without one."""
         r, w = self._ct.c_int(), self._ct.c_int()
