@@ -378,6 +378,35 @@ int amt_slab_barrier(amt_slab *slab);
 int amt_slab_max(amt_slab *slab, double *x);
 
 /* ------------------------------------------------------------------------
+ * (5b) Patches in i AND j (domains whose j extent is too small for one slab per GPU): rank
+ *      rj * pi + ri owns patch (ri, rj) of a pi x pj decomposition -- columns its..ite and rows jts..jte of the domain in a
+ *      resident handle whose memory holds at least one more column and row on every side that has a neighbour (GLOBAL ids..jde,
+ *      LOCAL ims <= its-1, ime >= ite+1, jms = jts-1, jme = jte+1).  Rows cross a boundary as in (5).  Across an i boundary the
+ *      stencil reads column ite+1 of u, u_1, t_1, muu, msfuy (module_small_step_em.f90:145-146, :244) and column its-1 of t_1
+ *      (:245): a column is kdim*jdim elements at stride idim, so one HIP kernel gathers the columns a patch sends into one
+ *      contiguous buffer per direction, the buffers travel in the same exchange as the rows (same transports, same flags), and
+ *      one kernel scatters what arrived into the halo columns.  No diagonal neighbours are needed.  Interior cells compute on
+ *      the domain's stream beside the exchange; the boundary rows (over the patch's whole width: they own the corners) and the
+ *      boundary columns (over the rows in between) follow it on the communication stream.  amt_slab_* is the pi = 1 case of the
+ *      same stepper.  Flags are enum amt_slab_flags (AMT_SLAB_LOOPBACK: the rank is its own neighbour on all four sides).
+ * ------------------------------------------------------------------------ */
+typedef struct amt_grid amt_grid;
+int amt_grid_create(amt_grid **out, amt_domain *domain, int ri, int rj, int pi, int pj,
+                    const void *unique_id, int flags);               /* collective over the pi * pj ranks */
+int amt_grid_destroy(amt_grid *grid);
+int amt_grid_exchange(amt_grid *grid);                               /* pack, exchange, unpack alone      */
+int amt_grid_step(amt_grid *grid, int n_sweeps);                     /* asynchronous                      */
+int amt_grid_step_timed(amt_grid *grid, int n_sweeps, float *ms_total);
+int amt_grid_sync(amt_grid *grid);
+int amt_grid_set_skew_us(amt_grid *grid, int microseconds);          /* test hook, as amt_slab_set_skew_us */
+long amt_grid_halo_bytes(const amt_grid *grid);                      /* sent + received by this rank per sweep */
+const char *amt_grid_transport(const amt_grid *grid);
+const char *amt_grid_pull_mode(const amt_grid *grid);
+int amt_grid_comm_info(const amt_grid *grid, int *rank, int *world);
+int amt_grid_barrier(amt_grid *grid);
+int amt_grid_max(amt_grid *grid, double *x);
+
+/* ------------------------------------------------------------------------
  * (6) Profiling aid: a plain streaming copy of nbytes (device to device) that moves
  *     bytes_per_lane = 4, 8 or 16 bytes per lane per access -- a KNOWN byte count in
  *     the kernels' own access width, used to calibrate rocprofv3's FETCH_SIZE /

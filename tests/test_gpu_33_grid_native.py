@@ -1,0 +1,146 @@
+"""SURVEY.md section 8f row 4 behind the C-ABI: amt_grid_* -- patches in i AND j with HIP pack / unpack kernels for the strided
+halo columns of u, u_1, t_1, muu, msfuy (the i+1 / i-1 reads of module_small_step_em.f90:145-146, 244-245), rows in place,
+one exchange for both, interior beside it.  (a) one rank as its own neighbour on all four sides (loopback: RCCL and IPC) against
+the ORACLE on the same arrays with the halo rows and columns copied by hand; (b) 2 x 2 and 3 x 2 real processes on cuda:0 over
+the IPC transport, NaN-poisoned halos, against the UNSPLIT oracle run."""
+import ctypes
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+ROOT = Path(__file__).resolve().parent.parent
+WORKER = ROOT / "tests" / "workers" / "grid_ipc_rank.py"
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    return torch
+
+
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "no-overlap"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_loopback_rows_and_packed_columns_against_the_oracle(pkg, oracle, torch_mod, dtype, overlap, transport):
+    """The middle patch of 3 x 3.  After the exchange row jte+1 of v, v_1, t_1, muv, msfvx_inv holds the patch's own row jts,
+    row jts-1 of t_1 its own row jte, column ite+1 of u, u_1, t_1, muu, msfuy its own column its, column its-1 of t_1 its own
+    column ite.  Expected: the oracle on host arrays with exactly those rows and columns copied by hand, three sweeps."""
+    S = pkg.synth
+    gdims = (190, 14, 45)
+    pb = S.patch_bounds(S.domain_bounds(*gdims), 1, 1, 3, 3, align_elems=32)
+    cfg = pkg.GridConfig()
+    dev = S.make_patch(pb, cfg, dtype=dtype, seed=41, global_dims=gdims, device="cuda:0")
+    want = dev.to_host()
+    a, cf, cl = dev.arrays, pb.its - pb.ims, pb.ite - pb.ims
+    nan = float("nan")
+    for n in S.HALO_FROM_ABOVE:
+        a[n][-1].fill_(nan)
+    a["t_1"][0].fill_(nan)
+    for n in pkg.patch.HALO_FROM_RIGHT:
+        a[n][..., cl + 1].fill_(nan)
+    a["t_1"][..., cf - 1].fill_(nan)
+    torch_mod.cuda.synchronize()
+    w = want.arrays
+    for n in S.HALO_FROM_ABOVE:
+        w[n][-1] = w[n][1]
+    w["t_1"][0] = w["t_1"][-2]
+    # the exchange moves rows first and columns in the same step: a column buffer holds the column as it was BEFORE this
+    # exchange's rows landed, i.e. its halo-row cells are the sender's old ones -- never read by the stencil (no diagonals);
+    # mirror that: columns from the pre-exchange arrays' owned rows only
+    for n in pkg.patch.HALO_FROM_RIGHT:
+        w[n][1:-1, ..., cl + 1] = w[n][1:-1, ..., cf]
+    w["t_1"][1:-1, ..., cf - 1] = w["t_1"][1:-1, ..., cl]
+    st = pkg.patch.NativeGridStepper(dev, 0, 0, 1, 1, pkg.patch.NativeGridStepper.comm_unique_id(), loopback=True, overlap=overlap,
+                                     transport=transport)
+    try:
+        assert st.transport() == transport and st.halo_bytes_per_sweep() > 0
+        st.step(3)
+        st.sync()
+    finally:
+        st.close()
+    for _ in range(3):
+        oracle.advance_mu_t(*want.args())
+    got = dev.to_host()
+    own = (slice(1, -1), Ellipsis, slice(cf, cl + 1))
+    for n in S.OUTPUTS:
+        assert np.isfinite(got.arrays[n][own]).all(), n
+        assert bits_equal(got.arrays[n][own], want.arrays[n][own]), f"{n} differs from the oracle"
+    # the halo cells the stencil reads hold what was sent
+    for n in pkg.patch.HALO_FROM_RIGHT:
+        assert bits_equal(got.arrays[n][1:-1, ..., cl + 1], want.arrays[n][1:-1, ..., cl + 1]), n
+    assert bits_equal(got.arrays["t_1"][1:-1, ..., cf - 1], want.arrays["t_1"][1:-1, ..., cf - 1])
+
+
+def test_a_patch_without_its_halo_column_is_refused(pkg, torch_mod):
+    from wrf_model_cuda_sample_amd import lib
+    S = pkg.synth
+    gdims = (64, 8, 16)
+    pb = S.patch_bounds(S.domain_bounds(*gdims), 1, 0, 3, 1, align_elems=1)
+    tight = pb.replace(ims=pb.its, ime=pb.ite)                      # no halo column in memory
+    dev = S.make_patch(tight, pkg.GridConfig(), dtype=np.float64, seed=1, global_dims=gdims, device="cuda:0")
+    with pytest.raises(lib.AmtError) as e:
+        pkg.patch.NativeGridStepper(dev, 0, 0, 1, 1, pkg.patch.NativeGridStepper.comm_unique_id(), loopback=True)
+    assert e.value.status == lib.ERR_PRECONDITION and "halo column" in str(e.value)
+
+
+def _run_ranks(tmp_path, pi, pj, dims, *, dtype="f64", sweeps=2, overlap=True, specified=False, align=32):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(AMT_RENDEZVOUS_NONCE=f"grid-{tmp_path.name}", AMT_SLAB_TRANSPORT="ipc", AMT_IPC_DEVICE_TIMEOUT_S="20",
+               AMT_IPC_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(pi * pj):
+        cmd = [sys.executable, str(WORKER), "--rank", str(r), "--grid", str(pi), str(pj), "--dir", str(tmp_path), "--dims",
+               *map(str, dims), "--dtype", dtype, "--sweeps", str(sweeps), "--align", str(align)]
+        cmd += [] if overlap else ["--no-overlap"]
+        cmd += ["--specified"] if specified else []
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=420)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung:\n" + "\n".join(outs))
+    assert [p.returncode for p in procs] == [0] * (pi * pj), "\n".join(outs)
+    return outs
+
+
+def _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, pi, pj, dims, dtype, sweeps, specified, align):
+    S = pkg.synth
+    np_dtype = np.float64 if dtype == "f64" else np.float32
+    gb = S.domain_bounds(*dims)
+    full = S.make_patch(gb, pkg.GridConfig(specified=specified), dtype=np_dtype, seed=17, global_dims=dims)
+    for _ in range(sweeps):
+        oracle.advance_mu_t(*full.args())
+    for r in range(pi * pj):
+        b = S.patch_bounds(gb, r % pi, r // pi, pi, pj, align_elems=align)
+        for n in S.OUTPUTS:
+            got = np.load(tmp_path / f"out_{r}_{n}.npy")
+            want = full.arrays[n][b.jts - gb.jms: b.jte - gb.jms + 1, ..., b.its - gb.ims: b.ite - gb.ims + 1]
+            assert bits_equal(got, want), f"rank {r} patch ({r % pi},{r // pi}): {n} differs from the unsplit oracle run"
+
+
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "no-overlap"])
+def test_2x2_processes_on_one_device_match_the_unsplit_oracle(pkg, oracle, tmp_path, overlap):
+    dims = (300, 24, 80)
+    outs = _run_ranks(tmp_path, 2, 2, dims, overlap=overlap, specified=True)
+    assert all("transport ipc, ranks seen 4" in o for o in outs), outs
+    _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 2, 2, dims, "f64", 2, True, 32)
+
+
+def test_3x2_processes_uneven_patches_fp32_unaligned_rows(pkg, oracle, tmp_path):
+    """The middle column of patches has a neighbour on every side but one; 151 columns over 3, 37 rows over 2; WRF's own
+    unpadded memory (ims = its-1)."""
+    dims = (151, 20, 37)
+    _run_ranks(tmp_path, 3, 2, dims, dtype="f32", sweeps=3, align=1)
+    _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 3, 2, dims, "f32", 3, False, 1)

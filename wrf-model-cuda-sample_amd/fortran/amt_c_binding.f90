@@ -7,6 +7,8 @@ MODULE amt_c_binding
    implicit none
 
    integer(c_int), parameter :: AMT_OK = 0
+   ! enum amt_slab_flags (amt_slab_create / amt_grid_create)
+   integer(c_int), parameter :: AMT_SLAB_NO_OVERLAP = 1, AMT_SLAB_LOOPBACK = 2, AMT_SLAB_TRANSPORT_IPC = 4
 
    interface
       ! (1) one-shot host drop-ins
@@ -244,6 +246,65 @@ MODULE amt_c_binding
       function amt_slab_max(slab, x) bind(C, name="amt_slab_max") result(rc)
          import :: c_ptr, c_int, c_double
          type(c_ptr), value :: slab
+         real(c_double) :: x                                 ! in: this rank's value, out: the maximum
+         integer(c_int) :: rc
+      end function
+
+      ! (5b) patches in i and j: rank = rj * pi + ri of pi x pj (amt_slab_* is the pi = 1 case)
+      function amt_grid_create(grid, domain, ri, rj, pi, pj, unique_id, flags) bind(C, name="amt_grid_create") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr) :: grid                         ! amt_grid **
+         type(c_ptr), value :: domain, unique_id     ! unique_id may be c_null_ptr when pi * pj == 1
+         integer(c_int), value :: ri, rj, pi, pj, flags
+         integer(c_int) :: rc
+      end function
+      function amt_grid_destroy(grid) bind(C, name="amt_grid_destroy") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: grid
+         integer(c_int) :: rc
+      end function
+      function amt_grid_exchange(grid) bind(C, name="amt_grid_exchange") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: grid
+         integer(c_int) :: rc
+      end function
+      function amt_grid_step(grid, n_sweeps) bind(C, name="amt_grid_step") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: grid
+         integer(c_int), value :: n_sweeps
+         integer(c_int) :: rc
+      end function
+      function amt_grid_step_timed(grid, n_sweeps, ms_total) bind(C, name="amt_grid_step_timed") result(rc)
+         import :: c_ptr, c_int, c_float
+         type(c_ptr), value :: grid
+         integer(c_int), value :: n_sweeps
+         real(c_float) :: ms_total
+         integer(c_int) :: rc
+      end function
+      function amt_grid_sync(grid) bind(C, name="amt_grid_sync") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: grid
+         integer(c_int) :: rc
+      end function
+      function amt_grid_halo_bytes(grid) bind(C, name="amt_grid_halo_bytes") result(n)
+         import :: c_ptr, c_long
+         type(c_ptr), value :: grid
+         integer(c_long) :: n
+      end function
+      function amt_grid_comm_info(grid, rank, world) bind(C, name="amt_grid_comm_info") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: grid
+         integer(c_int) :: rank, world
+         integer(c_int) :: rc
+      end function
+      function amt_grid_barrier(grid) bind(C, name="amt_grid_barrier") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: grid
+         integer(c_int) :: rc
+      end function
+      function amt_grid_max(grid, x) bind(C, name="amt_grid_max") result(rc)
+         import :: c_ptr, c_int, c_double
+         type(c_ptr), value :: grid
          real(c_double) :: x                                 ! in: this rank's value, out: the maximum
          integer(c_int) :: rc
       end function

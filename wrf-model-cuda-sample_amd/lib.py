@@ -98,6 +98,19 @@ SYMBOLS = {
     "amt_slab_comm_info": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "amt_slab_barrier": (_I, [_P]),
     "amt_slab_max": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
+    "amt_grid_create": (_I, [ctypes.POINTER(_P), _P, _I, _I, _I, _I, _P, _I]),
+    "amt_grid_destroy": (_I, [_P]),
+    "amt_grid_exchange": (_I, [_P]),
+    "amt_grid_step": (_I, [_P, _I]),
+    "amt_grid_step_timed": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
+    "amt_grid_sync": (_I, [_P]),
+    "amt_grid_set_skew_us": (_I, [_P, _I]),
+    "amt_grid_halo_bytes": (_L, [_P]),
+    "amt_grid_transport": (ctypes.c_char_p, [_P]),
+    "amt_grid_pull_mode": (ctypes.c_char_p, [_P]),
+    "amt_grid_comm_info": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "amt_grid_barrier": (_I, [_P]),
+    "amt_grid_max": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
     "amt_march_force_shape": (_I, [_I] * 7),
     "amt_march_rows_for": (_I, [ctypes.c_long, _I, _I, ctypes.c_long, _I, _I]),
     "amt_march_set_xchunk": (_I, [_I]),

@@ -191,10 +191,17 @@ class GridStepper:
     """
 
     def __init__(self, patch: Patch, ri: int, rj: int, pi: int, pj: int, compute: Callable, *,
-                 group=None, variant: int = 0, stage_through_host: bool = False):
+                 group=None, variant: int = 0, stage_through_host: bool = False,
+                 native: Optional[str] = None, unique_id: Optional[bytes] = None, overlap: bool = True):
         self.patch, self.ri, self.rj, self.pi, self.pj = patch, ri, rj, pi, pj
         self.compute, self.group, self.variant = compute, group, variant
         self.stage_through_host = stage_through_host
+        # native="rccl" | "ipc": a device patch is stepped by the C++ runtime (amt_grid_*: HIP pack / unpack kernels, one
+        # exchange, interior beside it) and this class only forwards; None: the torch.distributed path below (CPU tensors
+        # over gloo in the tests; device tensors staged through the host for bring-up)
+        self._native = None
+        if native is not None:
+            self._native = NativeGridStepper(patch, ri, rj, pi, pj, unique_id, overlap=overlap, variant=variant, transport=native)
         rank = lambda i, j: j * pi + i
         self.left = rank(ri - 1, rj) if ri > 0 else None
         self.right = rank(ri + 1, rj) if ri < pi - 1 else None
@@ -211,6 +218,8 @@ class GridStepper:
         return a[..., c]                                   # (jdim, kdim) or (jdim,) strided view
 
     def exchange_halos(self):
+        if self._native is not None:
+            return self._native.exchange_halos()
         dist = _dist()
         a = self.patch.arrays
         jdim = self.patch.bounds.jdim
@@ -253,6 +262,8 @@ class GridStepper:
             view.copy_(buf)
 
     def step(self):
+        if self._native is not None:
+            return self._native.step(1)
         self.exchange_halos()
         args = self.patch.args()
         if self.on_gpu:
@@ -377,6 +388,103 @@ class NativeSlabStepper:
             with self._dev():
                 self.L.amt_slab_destroy(self._slab)
             self._slab = self._ct.c_void_p()
+        if self._dom:
+            self.L.amt_domain_destroy(self._dom)
+            self._dom = self._ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeGridStepper:
+    """advance_mu_t on patch (ri, rj) of pi x pj driven by the C++ runtime behind the C-ABI (``amt_grid_*``, header section 5b):
+    HIP pack / unpack kernels for the strided halo columns, rows and packed columns in ONE exchange (RCCL group or IPC
+    pulls), interior cells on the patch's stream beside it, boundary rows and columns behind it on the communication stream.
+    Same construction as ``NativeSlabStepper`` (which is its pi = 1 case); rank = rj * pi + ri.
+    """
+
+    NO_OVERLAP, LOOPBACK, TRANSPORT_IPC = 1, 2, 4          # enum amt_slab_flags
+
+    def __init__(self, patch: Patch, ri: int, rj: int, pi: int, pj: int, unique_id: Optional[bytes] = None, *,
+                 stream=None, overlap: bool = True, variant: int = 0, loopback: bool = False, transport: str = "rccl"):
+        import ctypes
+        import torch
+        from . import lib as _lib
+        from .synth import FIELD_NAMES
+        self._lib, self._ct = _lib, ctypes
+        self.L = L = _lib.load_library()
+        self.patch, self.ri, self.rj, self.pi, self.pj = patch, ri, rj, pi, pj
+        t0 = patch.arrays["t_1"]
+        if not t0.is_cuda:
+            raise TypeError("NativeGridStepper needs a device patch (there is no CPU path)")
+        if transport not in ("rccl", "ipc"):
+            raise ValueError("transport is 'rccl' or 'ipc'")
+        b = patch.bounds
+        for name in FIELD_NAMES:
+            t = patch.arrays[name]
+            if not (t.is_cuda and t.dtype == t0.dtype and t.is_contiguous() and tuple(t.shape) == tuple(b.shape(name))):
+                raise TypeError(f"{name}: need a contiguous device tensor of shape {b.shape(name)}")
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=t0.device)
+        self.device_index = t0.device.index if t0.device.index is not None else torch.cuda.current_device()
+        fields = (ctypes.c_void_p * len(FIELD_NAMES))(*[patch.arrays[n].data_ptr() for n in FIELD_NAMES])
+        self._dom, self._grid = ctypes.c_void_p(), ctypes.c_void_p()
+        with torch.cuda.device(self.device_index):
+            _lib.check(L.amt_domain_wrap(ctypes.byref(self._dom), t0.element_size(), *patch.config.as_ints(),
+                                         *b.as_tuple(), fields, ctypes.c_void_p(self.stream.cuda_stream)))
+            try:
+                _lib.check(L.amt_domain_set_scalars(self._dom, patch.rdx, patch.rdy, patch.dts, patch.epssm))
+                _lib.check(L.amt_domain_set_variant(self._dom, int(variant)))
+                flags = ((0 if overlap else self.NO_OVERLAP) | (self.LOOPBACK if loopback else 0)
+                         | (self.TRANSPORT_IPC if transport == "ipc" else 0))
+                uid = None
+                if unique_id is not None:
+                    uid = (ctypes.c_char * 128).from_buffer_copy(bytes(unique_id))
+                _lib.check(L.amt_grid_create(ctypes.byref(self._grid), self._dom, ri, rj, pi, pj, uid, flags))
+            except BaseException:
+                L.amt_domain_destroy(self._dom)
+                self._dom = ctypes.c_void_p()
+                raise
+
+    comm_unique_id = staticmethod(NativeSlabStepper.comm_unique_id)
+
+    def _dev(self):
+        import torch
+        return torch.cuda.device(self.device_index)
+
+    def step(self, n_sweeps: int = 1):
+        with self._dev():
+            self._lib.check(self.L.amt_grid_step(self._grid, int(n_sweeps)))
+
+    def exchange_halos(self):
+        with self._dev():
+            self._lib.check(self.L.amt_grid_exchange(self._grid))
+
+    def sync(self):
+        with self._dev():
+            self._lib.check(self.L.amt_grid_sync(self._grid))
+
+    def halo_bytes_per_sweep(self) -> int:
+        return int(self.L.amt_grid_halo_bytes(self._grid))           # sent + received
+
+    def transport(self) -> str:
+        return self.L.amt_grid_transport(self._grid).decode()
+
+    def pull_mode(self) -> str:
+        return self.L.amt_grid_pull_mode(self._grid).decode()
+
+    def comm_info(self):
+        r, w = self._ct.c_int(), self._ct.c_int()
+        self._lib.check(self.L.amt_grid_comm_info(self._grid, self._ct.byref(r), self._ct.byref(w)))
+        return r.value, w.value
+
+    def close(self):
+        if self._grid:
+            with self._dev():
+                self.L.amt_grid_destroy(self._grid)
+            self._grid = self._ct.c_void_p()
         if self._dom:
             self.L.amt_domain_destroy(self._dom)
             self._dom = self._ct.c_void_p()
