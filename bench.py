@@ -99,6 +99,11 @@ def parse():
     ap.add_argument("--beside-reserve", type=int, default=0,
                     help="N > 1: compute units every round of the interior launch leaves free for the exchange and the edge rows "
                          "(profiles/r05_slab_ab.md: 4 rounds / 16 units make the sweep flat in the neighbours' lateness)")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="N > 1 plumbing without GPUs (tests/test_bench_dry_run.py): the ranks hold CPU tensors over gloo and run "
+                         "the same launcher, slabs, halo exchange, verification, reductions and teardown; the compute callable is "
+                         "NOT in this file -- the caller injects it (bench.DRY_RUN_COMPUTE); prints a line marked dry_run, never "
+                         "a measurement")
     ap.add_argument("--comm-timeout", type=float, default=120.0,
                     help="N > 1: most seconds a rank waits in the communicator set-up (ncclCommInitRank) and in the "
                          "first halo exchange before it ends itself with a diagnosis")
@@ -569,7 +574,8 @@ def self_launch(a):
                        AMT_RENDEZVOUS_NONCE=nonce, AMT_BENCH_SELF_LAUNCHED="1")
             if env.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":     # unset, or the image's quiet default
                 env["NCCL_DEBUG"] = "WARN"
-            p = subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+            # the ranks run the script this process was started as (bench.py; or the test shim that injects --cpu-dry-run's compute)
+            p = subprocess.Popen([sys.executable, str(Path(sys.argv[0]).resolve())] + sys.argv[1:], env=env,
                                  stdout=None if r == 0 else subprocess.PIPE, stderr=subprocess.PIPE,
                                  start_new_session=True)
             procs.append(p)
@@ -614,6 +620,73 @@ def self_launch(a):
 
 class StepTimeout(RuntimeError):
     pass
+
+
+# --cpu-dry-run: callable(*the 48 advance_mu_t arguments) that updates a tile of CPU tensors in place.  There is no CPU
+# implementation in the product: tests/workers/bench_cpu_shim.py sets this to the oracle (test infrastructure) before main().
+DRY_RUN_COMPUTE = None
+
+
+def dry_run_rank(a):
+    """One rank of `python <shim> --gpus N --cpu-dry-run`: everything of the N > 1 path that is not the GPU -- the
+    self-launcher's environment, the gloo group, slab_bounds, the poisoned halos and the torch.distributed exchange of
+    patch.SlabStepper, the first-sweep verification, barriers, max over ranks, the JSON line, the teardown."""
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    if DRY_RUN_COMPUTE is None:
+        raise SystemExit("bench.py --cpu-dry-run: no compute callable injected (bench.DRY_RUN_COMPUTE); the product has no CPU path")
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if os.environ.get("AMT_BENCH_TEST_DIE_RANK") == str(rank):     # tests/test_bench_dry_run.py: a rank that dies before the group forms
+        print(f"rank {rank} exiting with code 7 for the teardown test", file=sys.stderr, flush=True)
+        os._exit(7)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(60.0, a.comm_timeout)))
+    pkg = g.load_package()
+    S = pkg.synth
+    dtype = np.float64 if a.dtype == "f64" else np.float32
+    dims = (a.ni, a.nk, a.nj)
+    gb = S.domain_bounds(*dims, aligned=True, align_elems=a.align_elems)
+    sb = S.slab_bounds(gb, rank, world)
+    host = S.make_patch(sb, pkg.GridConfig(), dtype=dtype, seed=a.seed, global_dims=dims)
+    arrays = {k: torch.from_numpy(v) for k, v in host.arrays.items()}
+    if rank < world - 1:
+        for name in S.HALO_FROM_ABOVE:
+            arrays[name][-1].fill_(float("nan"))
+    if rank > 0:
+        arrays["t_1"][0].fill_(float("nan"))
+    patch = S.Patch(sb, host.config, arrays, host.rdx, host.rdy, host.dts, host.epssm, dims)
+    stepper = pkg.patch.SlabStepper(patch, rank, world, DRY_RUN_COMPUTE)
+    dist.barrier()
+    stepper.step()
+    oracle = g.load_oracle()                                     # the checker, as in the GPU path
+    verified, why = verify_first_sweep(pkg, oracle, patch, gb, dims, dtype, a.seed, (sb.jts, sb.jte))
+    for _ in range(max(a.warmup - 1, 0)):
+        stepper.step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        stepper.step()
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    t = torch.tensor([wall, 1.0 if verified else 0.0], dtype=torch.float64)
+    tmax, tmin = t.clone(), t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "note": "CPU plumbing run of the N > 1 path with an injected compute callable: not a measurement",
+                          "n_gpus": world, "ranks_seen": dist.get_world_size(), "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(float(tmax[0]) * 1e3 / max(a.steps, 1), 4), "verified_vs_oracle": bool(tmin[1] > 0.5),
+                          "verify_message": why or None, "scaling": "strong",
+                          "config": {"workload": f"advance_mu_t {a.ni}x{a.nk}x{a.nj} {a.dtype}, {world} j-slab(s)",
+                                     "rows_per_rank": [S.slab_bounds(gb, r, world).jte - S.slab_bounds(gb, r, world).jts + 1 for r in range(world)],
+                                     "halo_transport": "gloo (CPU tensors)", "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep()},
+                          "launched_by": "bench.py self-launch" if os.environ.get("AMT_BENCH_SELF_LAUNCHED") else "external launcher"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not bool(tmin[1] > 0.5):
+        raise SystemExit(3)
 
 
 def watchdog(fn, seconds, what):
@@ -1049,6 +1122,8 @@ def main():
         return emulate_one_rank(a)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         raise SystemExit(self_launch(a))
+    if a.cpu_dry_run:
+        return dry_run_rank(a)
     return run_rank(a)
 
 

@@ -64,6 +64,7 @@ def _worker(rank, world, port, shape, flags, sweeps, out_dir):
     (2, (20, 5, 9), dict(specified=True)),
     (3, (18, 4, 7), dict(nested=True)),      # middle slab has two neighbours; a 2-row slab
     (3, (12, 3, 3), dict()),                 # one-row slabs
+    (8, (24, 5, 61), dict(specified=True)),  # the target N, uneven rows (7 and 8 per rank), clipped outermost rows
 ])
 def test_slabs_reproduce_the_unsplit_domain(tmp_path, world, shape, flags):
     sweeps = 2
@@ -148,6 +149,7 @@ def _grid_worker(rank, world, port, shape, flags, pi, pj, sweeps, out_dir):
     (2, 1, (21, 5, 6), dict()),
     (2, 2, (17, 4, 9), dict(specified=True)),
     (3, 2, (20, 3, 7), dict(nested=True, periodic_x=True)),
+    (4, 2, (29, 3, 11), dict(specified=True)),            # eight ranks, uneven in both directions
 ])
 def test_2d_patches_reproduce_the_unsplit_domain(tmp_path, pi, pj, shape, flags):
     """i x j decomposition: packed column halos + row halos, NaN-poisoned."""
