@@ -71,7 +71,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=256,
                     help="j rows of the CPU-baseline slab sample (at least one per granted core; capped by free host memory)")
-    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the whole CPU-baseline leg, fill time included")
+    ap.add_argument("--cpu-seconds", type=float, default=100.0,
+                    help="budget of the whole CPU-baseline leg, fill time included (the whole-domain entry runs only if its estimate fits)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU projection: do the per-sweep work of ONE rank of an N-slab run (interior + "
                          "edge launches, second stream, halo rows copied device-to-device from local buffers); "
@@ -401,19 +402,19 @@ def cpu_baseline(dims, dtype_name, seed, rows, seconds):
     t_leg = time.perf_counter()
 
 
-    def run(impl, shape, threads, what="", gj0=0, gnj=0, share=1.0):
+    def run(impl, shape, threads, what="", gj0=0, gnj=0, share=1.0, sweep_seconds=None, timeout=None):
         left = seconds - (time.perf_counter() - t_leg)
         if left <= 0.5:
             errors.append(f"{impl} {shape} x{threads}: skipped, the leg's {seconds:.0f} s budget is spent")
             return None
-        budget = max(0.3, min(left, seconds * share / 12.0))
+        budget = sweep_seconds if sweep_seconds else max(0.3, min(left, seconds * share / 12.0))
         cmd = [sys.executable, worker, "--impl", impl, "--dtype", dtype_name, "--size", *map(str, shape),
                "--threads", str(threads), "--seconds", f"{budget:.2f}", "--seed", str(seed), "--gj0", str(gj0), "--gnj", str(gnj)]
         try:
             # (no ORACLE_BENCH_FILL_THREADS for the one-thread entries: on a two-socket host the pages a parallel
             # fill touches land on both sockets and the single compute thread then reads half its data remotely:
             # 151 against 229 Mcells/s for the same code on 2 x EPYC 9575F)
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(45.0, 4 * left))
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout or max(45.0, 4 * left))
             if r.returncode != 0:
                 raise RuntimeError(f"exit {r.returncode}: {r.stderr.strip()[-300:]}")
             rec = json.loads(r.stdout.strip().splitlines()[-1])
@@ -445,10 +446,38 @@ def cpu_baseline(dims, dtype_name, seed, rows, seconds):
     run("c", (512, 60, 512), cores)
     if (ROOT / "oracle" / "_ref" / f"libref_amt_{dtype_name}.so").exists():
         run("reference", (64, 40, 64), 1)
+    # The whole bench domain where the host allows ("the largest size host RAM allows"):
+    # MemAvailable at least twice the domain, and the estimate -- the slab entry's fill and sweep times scaled by the rows --
+    # inside what is left of the leg's budget.  Pages are first touched by the threads that compute on them, like the slab.
+    # The slab sample stays the fallback; the record says which one `value` is.
+    full, full_skipped = None, None
+    domain_bytes = row_bytes * (nj + 2)
+    best_slab = max((c for c in (slab_f, slab_c) if c), key=lambda c: c["Mcells_s"], default=None)
+    if slab_rows >= nj:
+        full_skipped = "the slab sample IS the whole domain"
+    elif not avail or avail < 2 * domain_bytes:
+        full_skipped = f"MemAvailable {(avail or 0) / 2**30:.0f} GiB is less than twice the domain's {domain_bytes / 2**30:.0f} GiB"
+    elif not best_slab:
+        full_skipped = "no slab measurement to size it by"
+    else:
+        scale = nj / slab_rows
+        est = (best_slab["fill_s"] or 0.0) * scale + 5 * best_slab["ms_per_sweep"] * 1e-3 * scale + 3.0
+        left = seconds - (time.perf_counter() - t_leg)
+        if est > left - 2.0:
+            full_skipped = f"estimated {est:.0f} s (fill + 5 sweeps) does not fit the {left:.0f} s left of --cpu-seconds {seconds:.0f}"
+        else:
+            full_impl = "fortran" if best_slab is slab_f else "c"
+            full = run(full_impl, (ni, nk, nj), cores, "the whole bench domain, first touch by the computing threads", 0, nj,
+                       sweep_seconds=max(1.0, 4 * best_slab["ms_per_sweep"] * 1e-3 * scale), timeout=max(60.0, 3 * est))
+            if not full:
+                full_skipped = "the full-size entry failed (see errors)"
     # `value` is the FASTEST CPU path on the slab, all granted cores (a baseline must not be the
-    # slower of two measured paths); both are named, with their figures
+    # slower of two measured paths); both are named, with their figures -- or the same path on the whole domain
     cands = [c for c in (slab_f, slab_c) if c]
     slab = max(cands, key=lambda c: c["Mcells_s"]) if cands else None
+    slab_sample = slab
+    if full:
+        slab = full
     impls = {"fortran": "fortran: oracle/fortran/advance_mu_t_cpu.f90, the build's own Fortran-90 restatement (fused, i blocks "
                         "marching in j, OpenMP j-tiles; amdflang -O3 -march=native -ffp-contract=off; bit-equal to the "
                         "reference's outputs in tests/golden/)",
@@ -460,8 +489,13 @@ def cpu_baseline(dims, dtype_name, seed, rows, seconds):
            "value_is": "the faster of the Fortran CPU path and the C port on the same j-slab and cores",
            "fortran_Mcells_s": slab_f["Mcells_s"] if slab_f else None,
            "port_c_Mcells_s": slab_c["Mcells_s"] if slab_c else None,
-           "sample": f"{ni}x{nk}x{slab_rows} j-slab (rows {gj0 + 1}..{gj0 + slab_rows}) of the same synthetic domain, median sweep, "
-                     f"{slab['threads'] if slab else cores} OpenMP j-tiles, pages first touched by their tile's thread",
+           "sample": (f"the WHOLE {ni}x{nk}x{nj} domain of the bench line ({domain_bytes / 2**30:.0f} GiB of host arrays), median sweep, "
+                      f"{full['threads']} OpenMP j-tiles, pages first touched by their tile's thread" if full else
+                      f"{ni}x{nk}x{slab_rows} j-slab (rows {gj0 + 1}..{gj0 + slab_rows}) of the same synthetic domain, median sweep, "
+                      f"{slab['threads'] if slab else cores} OpenMP j-tiles, pages first touched by their tile's thread"),
+           "sample_is": "full domain" if full else "j-slab",
+           "full_domain_skipped_because": full_skipped,
+           "slab_sample_Mcells_s": slab_sample["Mcells_s"] if slab_sample else None,
            "ms_per_sweep_sample": slab["ms_per_sweep"] if slab else None,
            "fastest_sweep_Mcells_s": slab.get("Mcells_s_fastest_sweep") if slab else None,   # the host is shared: its best sweep beside the median
            "one_thread_Mcells_s": one["Mcells_s"] if one else None,
