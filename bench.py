@@ -7,8 +7,8 @@
 A "step" is one advance_mu_t sweep (one acoustic sub-step's call) over the whole
 4096 x 60 x 4096 fp64 domain (BASELINE.json configs[2]/[3]); inputs are resident in HBM before
 the timed region.  With N > 1 the SAME domain is split into N j-slabs (strong scaling), each
-rank trades its one-row input halos over RCCL send/recv every sweep while its interior rows
-compute.  Default N > 1 stepper: the native C++ runtime behind the C-ABI (amt_slab_*, the path a
+rank trades its one-row input halos every sweep (--transport rccl: ncclSend/ncclRecv; ipc: peer copies between
+processes, which may share one device) while its interior rows compute.  Default N > 1 stepper: the native C++ runtime behind the C-ABI (amt_slab_*, the path a
 Fortran host calls; patch.NativeSlabStepper hands it pointers); --stepper torch runs the same
 schedule through torch.distributed P2P ops (patch.SlabStepper) as a cross-check.  Both start from
 NaN-poisoned halo rows and are verified against the oracle after the first sweep.
@@ -17,11 +17,12 @@ Output keys beyond the driver's contract:
   roofline      algorithmic HBM bytes of one sweep (W*NI*NJ*(11*NK+14))
                 divided by the HIP-event time of the kernel launches, against 8 TB/s per GPU
   cpu_baseline  the fastest CPU path -- the build's Fortran-90 restatement or the C port, both j-tiled over the
-                host cores -- timed on a bounded j-slab sample of the same synthetic domain (rank 0, N=1)
-  placement     `value` is timed on the fastest of --probe-placements allocations of the state (disclosed in
-                config.placement_probe_ms); ms_per_step_placement_median / frac_placement_median /
-                value_placement_median say what an allocation AS IT COMES gives (the product's figure for a
-                host that calls amt_domain_create once) -- the timed sweeps scaled by median(probes) / min(probes)
+                host cores -- timed on the WHOLE domain where host memory and the leg's budget allow, else on a bounded
+                j-slab sample of it (rank 0, N=1; the record says which)
+  placement     the bench state is allocated by amt_domain_create (the product call a Fortran / C host makes once), whose
+                default placement sampling keeps the fastest of 4 allocations of the state: `value` is therefore what a
+                once-allocating host of the library gets; config.placement_probe_ms lists every allocation's sweep time
+                and placement.*_first_allocation says what hipMalloc as it comes would have given
 """
 from __future__ import annotations
 
@@ -53,11 +54,10 @@ def parse():
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 column, 2 march")
     ap.add_argument("--seed", type=int, default=12345)
-    ap.add_argument("--probe-placements", type=int, default=5,
-                    help="allocate the state this many times (one after the other), time 2 sweeps on each and keep "
-                         "the fastest: the sweep time depends on which physical pages the driver hands out (up to 5 %% "
-                         "between allocations, stable within one); every timing is reported; 1 = take the first "
-                         "allocation as it comes; skipped when two copies do not fit")
+    ap.add_argument("--probe-placements", type=int, default=0,
+                    help="placement sampling of amt_domain_create, which allocates the bench state: 0 = the library's default "
+                         "(AMT_DOMAIN_PLACEMENT_TRIES, 4 allocations of the state, the fastest kept), 1 = the first allocation as "
+                         "it comes, K = K allocations; every timing is reported (config.placement_probe_ms)")
     ap.add_argument("--idim-extra", type=int, default=0, help="extra elements of i padding at the end of each row")
     ap.add_argument("--align-elems", type=int, default=32,
                     help="i padding of the resident layout: i = its sits this many elements into a row")
@@ -808,44 +808,15 @@ def run_rank(a):
     # every launch, copy and event of this rank goes to ONE stream (torch's current one)
     main_stream = torch.cuda.Stream(device=device) if native else torch.cuda.current_stream(device)
     torch.cuda.set_stream(main_stream)
-    dev = S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device=device)
-    probe_ms = None
-    state_bytes = sum(t.numel() * t.element_size() for t in dev.arrays.values())
-    if a.probe_placements > 1 and torch.cuda.mem_get_info(device)[0] > 1.05 * state_bytes + (9 << 30):
-        # Placement probe.  Where the driver puts the arrays' pages moves this sweep by up to 5 % (same
-        # virtual addresses, fresh physical pages: 15.4 .. 16.2 ms in one process, profiles/r03_placement.md);
-        # nothing below 2 MiB of the addresses matters, so it cannot be steered -- only sampled.  Same data,
-        # K allocations one after the other (at most two resident at a time), two timed sweeps on each, the
-        # fastest is kept and refilled; every timing goes into the line (config.placement_probe_ms).
-        def timed2(cnd):
-            call = pkg.bind_device_call(*cnd.args(), variant=a.variant)
-            call()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); call(); call(); e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / 2
-        probe_ms = [round(timed2(dev), 3)]
-        best_ms = probe_ms[0]
-        for k in range(1, a.probe_placements):
-            spacer = torch.empty((k * 1237 + 311) << 20, dtype=torch.uint8, device=device)    # shifts what follows
-            cnd = S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device=device)
-            del spacer
-            ms = timed2(cnd)
-            probe_ms.append(round(ms, 3))
-            if ms < best_ms:
-                best_ms, dev = ms, cnd
-            del cnd
-            torch.cuda.empty_cache()                   # the loser's pages go back to the driver
-        # the probe advanced the state: refill the kept copy in place from the generator
-        L = pkg.load_library()
-        import ctypes as _ct
-        for name in S.FIELD_NAMES:
-            t = dev.arrays[name]
-            fa, _ = S._fill_args(sb, name, dims)
-            pkg.lib.check(L.amt_synth_fill_device(_ct.c_void_p(torch.cuda.current_stream().cuda_stream), S.FIELD_ID[name],
-                                                  t.element_size(), _ct.c_void_p(t.data_ptr()), _ct.c_uint64(a.seed), *fa))
-        torch.cuda.synchronize()
+    # The state is allocated by the PRODUCT: amt_domain_create, the call a Fortran or C host makes once, with its default
+    # placement sampling (AMT_DOMAIN_PLACEMENT_TRIES allocations of the state, the fastest kept: the sweep time depends on which
+    # physical pages the driver hands out, profiles/r05_placement.md).  The tensors below VIEW those arrays: `value` is what a
+    # once-allocating host gets.  --probe-placements K overrides the number of tries (1 = first as it comes).
+    if a.probe_placements > 0:
+        os.environ["AMT_DOMAIN_PLACEMENT_TRIES"] = str(a.probe_placements)
+    dev = S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device=device, native_domain=True)
+    probe_ms = dev.owner.placement_ms() or None
+    torch.cuda.synchronize()
     ceilings, clocks_under_load = None, None
     if not a.no_box_probe and torch.cuda.mem_get_info(device)[0] > (9 << 30):
         try:
@@ -1070,20 +1041,20 @@ def run_rank(a):
             out["note"] = (f"{world} ranks share {ndev} device(s): a correctness run of the whole N > 1 path (slabs, halo exchange, "
                            "verification, reductions); `value` is NOT a scaling measurement")
         if probe_ms and len(probe_ms) >= 2:
-            # What an UN-sampled placement gives: the K probes are the same two sweeps on K
-            # allocations of the same state; `value` was timed on the fastest of them.  The median probe over the
-            # fastest probe scales the timed figure to the allocation a host gets as it comes.
+            # The K probes are the same sweeps on K allocations of the same state, made and chosen by amt_domain_create itself:
+            # `value` is timed on the set it kept, i.e. on what ANY host of the library gets from one amt_domain_create.
             pm, pmin, p0 = float(np.median(probe_ms)), float(min(probe_ms)), float(probe_ms[0])
             out["placement"] = {
-                "selection": f"fastest of {len(probe_ms)} allocations of the state (bench-side sampling; --probe-placements 1 = none)",
+                "selection": f"amt_domain_create: fastest of {len(probe_ms)} allocations of the state (the library's default sampling; "
+                             "AMT_DOMAIN_PLACEMENT_TRIES=1 or --probe-placements 1 = the first as it comes)",
                 "probe_ms": probe_ms,
                 "ms_per_step_placement_median": round(ev_per_step_s * 1e3 * pm / pmin, 4),
                 "frac_placement_median": round(achieved / HBM_PEAK_GBS * pmin / pm, 4),
                 "value_placement_median": round(value * pmin / pm, 2),
                 "ms_per_step_first_allocation": round(ev_per_step_s * 1e3 * p0 / pmin, 4),
                 "frac_first_allocation": round(achieved / HBM_PEAK_GBS * pmin / p0, 4),
-                "note": "value / roofline.frac are measured on the fastest placement; the *_placement_median figures are what a "
-                        "host that allocates once (amt_domain_create, hipMalloc as it comes) should expect"}
+                "note": "value / roofline.frac are what a host that calls amt_domain_create once gets (the sampling is inside the "
+                        "product); the *_first_allocation figures are what hipMalloc as it comes would have given"}
         if ceilings and "box_copy_GBps" in ceilings:
             # Attribution of the sweep time to the box or to the kernel.  A copy moves one byte out per byte in;
             # this sweep reads 2.7x what it writes, and reads stream faster than writes, so the box's ceiling for

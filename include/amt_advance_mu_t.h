@@ -284,6 +284,11 @@ int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_total);
  * NULL) receives the sweep time of each set (0 for sets that were not tried).  Device pointers obtained from
  * amt_domain_field_ptr before the call are no longer valid.  Not for wrapped domains (amt_domain_wrap). */
 int amt_domain_tune_placement(amt_domain *domain, int tries, float *ms_per_try);
+/* amt_domain_create does the same sampling by itself for states of 256 MiB and more (AMT_DOMAIN_PLACEMENT_TRIES allocations, default
+ * 4; 0 or 1 = the first allocation as it comes; skipped where a second copy of the state does not fit): a host that creates its
+ * handle once gets the sweep time bench.py prints.  Returns the number of allocations timed by the last sampling of this handle
+ * (0: none) and their sweep times (ms; 0 for sets that were not tried). */
+int amt_domain_placement(const amt_domain *domain, float *ms_per_try, int cap);
 int amt_domain_sync(amt_domain *d);
 void *amt_domain_field_ptr(amt_domain *d, int field);   /* device pointer, NULL on error */
 void *amt_domain_stream(amt_domain *d);                 /* hipStream_t */

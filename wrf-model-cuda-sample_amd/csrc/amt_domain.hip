@@ -63,14 +63,40 @@ static int amt_domain_make(amt_domain **out, int dtype_bytes,
     return AMT_OK;
 }
 
+static int amt_domain_tune(amt_domain *d, int tries, float *ms_per_try, bool preserve);
+
 extern "C" int amt_domain_create(amt_domain **out, int dtype_bytes,
                                  int periodic_x, int specified, int nested,
                                  int ids, int ide, int jds, int jde, int kde,
                                  int ims, int ime, int jms, int jme, int kms, int kme,
                                  int its, int ite, int jts, int jte, int kts, int kte)
 {
-    return amt_domain_make(out, dtype_bytes, periodic_x, specified, nested, ids, ide, jds, jde, kde,
-                           ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte, nullptr, nullptr);
+    int rc = amt_domain_make(out, dtype_bytes, periodic_x, specified, nested, ids, ide, jds, jde, kde,
+                             ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte, nullptr, nullptr);
+    if (rc != AMT_OK) return rc;
+    // Placement sampling, on by default (a host that creates its handle ONCE must get the sweep time the
+    // bench prints).  Which physical pages the driver hands out moves a sweep of a large domain by +-3 % and cannot be steered
+    // (profiles/r03_placement.md, r05_placement.md: not the TLB, not the L2 channels -- below the L2), only sampled: the state
+    // is allocated AMT_DOMAIN_PLACEMENT_TRIES times (default 4; 0 or 1 = take the first as it comes), one set after the other,
+    // three sweeps of the handle's own kernel on each, the fastest kept.  Skipped for states under 256 MiB (nothing to gain), for
+    // windows the routine cannot run, and where a second copy does not fit.  The arrays hold nothing yet: no contents move.
+    amt_domain *d = *out;
+    int tries = 4;
+    if (const char *e = getenv("AMT_DOMAIN_PLACEMENT_TRIES")) tries = atoi(e);
+    if (tries > 16) tries = 16;
+    size_t state = 0;
+    for (int f = 0; f < AMT_F_COUNT; ++f) state += d->count(f) * (size_t)dtype_bytes;
+    size_t free_b = 0, total_b = 0;
+    if (tries > 1 && state >= ((size_t)256 << 20) && kts == 1 && kte == kde && hipMemGetInfo(&free_b, &total_b) == hipSuccess
+        && free_b > state + state / 16 + ((size_t)6 << 30)) {
+        float ms[16] = {};
+        if (amt_domain_tune(d, tries, ms, false) == AMT_OK) {
+            d->placement_tries = tries;
+            memcpy(d->placement_ms, ms, sizeof ms);
+        }
+        (void)hipGetLastError();                                  // a sampling that could not run costs nothing but itself
+    }
+    return AMT_OK;
 }
 
 extern "C" int amt_domain_wrap(amt_domain **out, int dtype_bytes,
@@ -206,10 +232,9 @@ extern "C" int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_tota
 // kernel on each, the fastest kept.  The contents of every array are what they were before the call (the in/out and output
 // arrays the timed sweeps advanced are restored from a copy).  bench.py does the same with its torch-owned arrays
 // (--probe-placements); a C / Fortran host gets the same memory this way.
-extern "C" int amt_domain_tune_placement(amt_domain *d, int tries, float *ms_per_try)
+// preserve = false (amt_domain_create: the arrays hold nothing yet): no copies at all, the candidates are timed as allocated
+static int amt_domain_tune(amt_domain *d, int tries, float *ms_per_try, bool preserve)
 {
-    if (!d || tries < 1) return amt_fail(AMT_ERR_INVALID_ARG, "bad tuning argument");
-    if (!d->owns_fields) return amt_fail(AMT_ERR_INVALID_ARG, "amt_domain_tune_placement: the arrays belong to the caller (amt_domain_wrap)");
     DeviceScope scope(d->device);
     static const int mutated[] = {AMT_F_WW, AMT_F_T, AMT_F_T_AVE, AMT_F_MU, AMT_F_MUAVE, AMT_F_MUTS, AMT_F_MUDF};
     auto bytes = [&](int f) { return d->count(f) * (size_t)d->dtype_bytes; };
@@ -232,6 +257,7 @@ extern "C" int amt_domain_tune_placement(amt_domain *d, int tries, float *ms_per
     hipError_t copy_err = hipSuccess;
     auto note = [&](hipError_t e) { if (e != hipSuccess && copy_err == hipSuccess) copy_err = e; };
     for (int f : mutated) {
+        if (!preserve) break;
         if (hipMalloc(&keep[f], bytes(f)) != hipSuccess) {
             (void)hipGetLastError();
             free_set(keep);
@@ -260,7 +286,7 @@ extern "C" int amt_domain_tune_placement(amt_domain *d, int tries, float *ms_per
             break;
         }
         hipError_t ce = hipSuccess;
-        for (int f = 0; f < AMT_F_COUNT && ce == hipSuccess; ++f) {
+        for (int f = 0; f < AMT_F_COUNT && ce == hipSuccess && preserve; ++f) {
             const bool mut = keep[f] != nullptr;
             ce = hipMemcpyAsync(cand[f], mut ? keep[f] : d->field[f], bytes(f), hipMemcpyDeviceToDevice, d->stream);
         }
@@ -285,12 +311,32 @@ extern "C" int amt_domain_tune_placement(amt_domain *d, int tries, float *ms_per
         }
     }
     for (int f : mutated)                                         // contents as they were before the call
-        note(hipMemcpyAsync(d->field[f], keep[f], bytes(f), hipMemcpyDeviceToDevice, d->stream));
+        if (preserve) note(hipMemcpyAsync(d->field[f], keep[f], bytes(f), hipMemcpyDeviceToDevice, d->stream));
     note(hipStreamSynchronize(d->stream));
     free_set(keep);
     if (copy_err != hipSuccess)
         return amt_fail(AMT_ERR_HIP, "amt_domain_tune_placement: restoring the output arrays failed: %s (their contents are undefined)", hipGetErrorString(copy_err));
     return rc;
+}
+
+extern "C" int amt_domain_tune_placement(amt_domain *d, int tries, float *ms_per_try)
+{
+    if (!d || tries < 1) return amt_fail(AMT_ERR_INVALID_ARG, "bad tuning argument");
+    if (!d->owns_fields) return amt_fail(AMT_ERR_INVALID_ARG, "amt_domain_tune_placement: the arrays belong to the caller (amt_domain_wrap)");
+    float ms[16] = {};
+    if (tries > 16) tries = 16;
+    const int rc = amt_domain_tune(d, tries, ms, true);
+    d->placement_tries = tries;
+    memcpy(d->placement_ms, ms, sizeof ms);
+    for (int k = 0; k < tries && ms_per_try; ++k) ms_per_try[k] = ms[k];
+    return rc;
+}
+
+extern "C" int amt_domain_placement(const amt_domain *d, float *ms_per_try, int cap)
+{
+    if (!d) return 0;
+    for (int k = 0; k < d->placement_tries && k < cap && ms_per_try; ++k) ms_per_try[k] = d->placement_ms[k];
+    return d->placement_tries;
 }
 
 extern "C" int amt_domain_sync(amt_domain *d)

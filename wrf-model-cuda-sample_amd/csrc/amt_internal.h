@@ -114,6 +114,8 @@ struct amt_domain {
     void *field[AMT_F_COUNT] = {};
     bool owns_fields = true;      // false: the arrays belong to the caller (amt_domain_wrap)
     bool owns_stream = true;      // false: the stream belongs to the caller
+    int placement_tries = 0;      // allocations of the state that were timed (amt_domain_create / amt_domain_tune_placement)
+    float placement_ms[16] = {};  // sweep time on each (0: not tried)
     size_t count(int f) const
     {
         const size_t idim = ime - ims + 1, kdim = kme - kms + 1, jdim = jme - jms + 1;

@@ -64,6 +64,7 @@ SYMBOLS = {
     "amt_domain_fill_synthetic": (_I, [_P, ctypes.c_uint64] + [_L] * 6),
     "amt_domain_step": (_I, [_P, _I]),
     "amt_domain_tune_placement": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
+    "amt_domain_placement": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
     "amt_domain_step_timed": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
     "amt_domain_sync": (_I, [_P]),
     "amt_domain_field_ptr": (_P, [_P, _I]),

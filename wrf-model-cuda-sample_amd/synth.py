@@ -152,6 +152,7 @@ class Patch:
     dts: float = DTS
     epssm: float = EPSSM
     global_dims: tuple = _dc_field(default=())
+    owner: object = None          # make_patch(native_domain=True): the amt_domain handle whose device arrays the tensors view
 
     def args(self):
         """The 48 arguments in the order of module_small_step_em.f90:7-18."""
@@ -164,7 +165,7 @@ class Patch:
 
     def with_bounds(self, **kw) -> "Patch":
         return Patch(self.bounds.replace(**kw), self.config, self.arrays, self.rdx, self.rdy,
-                     self.dts, self.epssm, self.global_dims)
+                     self.dts, self.epssm, self.global_dims, self.owner)
 
     def copy(self) -> "Patch":
         arrays = {k: (v.clone() if hasattr(v, "clone") else v.copy()) for k, v in self.arrays.items()}
@@ -189,11 +190,50 @@ def _fill_args(b: Bounds, name: str, gdims):
     return (idim, kdim, jdim, b.ims, b.kms - 1, b.jms, gni + 2, gnk + 1, gnj + 2), r
 
 
+class NativeDomain:
+    """Owner of a resident handle made by ``amt_domain_create`` (the C-ABI a Fortran or C host calls, placement sampling
+    included) whose 26 device arrays torch tensors VIEW through ``__cuda_array_interface__``: a Python caller then holds
+    exactly the memory a native host would.  Destroyed with the last tensor that views it."""
+
+    def __init__(self, b: Bounds, config: GridConfig, itemsize: int):
+        self.L = _lib.load_library()
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.L.amt_domain_create(ctypes.byref(self.handle), itemsize, *config.as_ints(), *b.as_tuple()))
+
+    def placement_ms(self):
+        """Sweep time (ms) on every allocation of the state that amt_domain_create timed; [] when it did not sample."""
+        ms = (ctypes.c_float * 16)()
+        n = int(self.L.amt_domain_placement(self.handle, ms, 16))
+        return [round(float(ms[k]), 3) for k in range(n) if ms[k] > 0]
+
+    def view(self, field_id: int, shape, typestr: str):
+        ptr = self.L.amt_domain_field_ptr(self.handle, field_id)
+        if not ptr:
+            raise _lib.AmtError(_lib.ERR_INVALID_ARG, "amt_domain_field_ptr returned NULL")
+
+        class _View:                                   # keeps the owner alive for as long as a tensor views the array
+            pass
+        v = _View()
+        v.owner = self
+        v.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+        return v
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.L.amt_domain_destroy(self.handle)
+                self.handle = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
 def make_patch(b: Bounds, config: GridConfig = GridConfig(), dtype=np.float64, seed: int = 12345,
-               global_dims=None, device=None, stream=None) -> Patch:
+               global_dims=None, device=None, stream=None, native_domain: bool = False) -> Patch:
     """Fill all 26 arrays of a patch.  ``global_dims`` = (NI, NK, NJ) of the whole domain
     (default: derived from ``b`` assuming a single patch).  ``device=None`` -> numpy arrays
-    via amt_synth_fill_host; otherwise torch tensors on ``device`` via amt_synth_fill_device."""
+    via amt_synth_fill_host; otherwise torch tensors on ``device`` via amt_synth_fill_device.
+    ``native_domain``: the device arrays are those of an ``amt_domain_create`` handle (``Patch.owner``) -- what a C / Fortran
+    host holds, the library's default placement sampling included -- and the tensors view them."""
     L = _lib.load_library()
     if global_dims is None:
         global_dims = (b.ide - b.ids, b.kde - 1, b.jde - b.jds)
@@ -213,12 +253,20 @@ def make_patch(b: Bounds, config: GridConfig = GridConfig(), dtype=np.float64, s
         dev = torch.device(device)
         if stream is None:
             stream = torch.cuda.current_stream(dev)
+        owner = None
         with torch.cuda.device(dev):
+            if native_domain:
+                owner = NativeDomain(b, config, 8 if tdt == torch.float64 else 4)
             for name in FIELD_NAMES:
-                a = torch.empty(b.shape(name), dtype=tdt, device=dev)
+                if owner is not None:
+                    a = torch.as_tensor(owner.view(FIELD_ID[name], b.shape(name), "<f8" if tdt == torch.float64 else "<f4"), device=dev)
+                    assert a.dtype == tdt and tuple(a.shape) == tuple(b.shape(name))
+                else:
+                    a = torch.empty(b.shape(name), dtype=tdt, device=dev)
                 fa, _ = _fill_args(b, name, global_dims)
                 _lib.check(L.amt_synth_fill_device(ctypes.c_void_p(stream.cuda_stream), FIELD_ID[name],
                                                    a.element_size(), ctypes.c_void_p(a.data_ptr()),
                                                    ctypes.c_uint64(seed), *fa))
                 arrays[name] = a
+        return Patch(b, config, arrays, RDX, RDY, DTS, EPSSM, tuple(global_dims), owner)
     return Patch(b, config, arrays, RDX, RDY, DTS, EPSSM, tuple(global_dims))
