@@ -277,7 +277,7 @@ int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,
 int amt_domain_step(amt_domain *d, int n_sweeps);
 /* same, bracketed by HIP events on the domain's stream; returns after completion */
 int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_total);
-/* Placement tuning (speed only; +-3 % of a sweep hang on which physical pages the driver hands out, DESIGN.md 4.2):
+/* Placement tuning (speed only; +-3 % of a sweep hang on which physical pages the driver hands out, DESIGN.md 4.3):
  * allocates the handle's 26 arrays `tries` times, one set after the other (needs room for a second copy of the state;
  * stops early when there is none), copies the current contents over, times two sweeps of the handle's own kernel on each
  * set and keeps the fastest; every array holds afterwards what it held before the call.  ms_per_try (tries floats, or
@@ -442,7 +442,7 @@ int amt_march_selectable(char *buf, int cap);
 /* Rows per workgroup the launcher gives `ntile_i` column tiles of `nj` rows on `cus` compute units when a block's
  * unsigned 32-bit row offsets span at most `max_rows` rows, for a shape of `wbytes`-byte elements with `hl` level groups
  * per wave: the r <= max_rows that minimises rounds(r) * (r + 0.5), at most 64 for the fp64 shapes with level groups
- * (profiles/r04_rows.md).  Host arithmetic only; 0 when there is nothing to plan (no tile, row or CU). */
+ * (DESIGN.md section 4.2 "Launch plan", profiles/r04_rows.md).  Host arithmetic only; 0 when there is nothing to plan (no tile, row or CU). */
 int amt_march_rows_for(long ntile_i, int nj, int cus, long max_rows, int wbytes, int hl);
 /* Diagnosis: how workgroup numbers map to blocks.  0 (default): each XCD owns one contiguous run of blocks for the
  * whole launch; n > 0: every 8 n consecutive workgroup numbers cover 8 n consecutive blocks, n per XCD.  Which is

@@ -7,7 +7,7 @@ sweep starts that many microseconds late on the communication stream (amt_slab_s
 of the ncclSend/ncclRecv group), so this rank's halo rows arrive late while its interior rows compute: the sweep time
 against the skew shows how much skew the overlap absorbs (about the interior's run time minus exchange and edge rows)
 before it shows up one for one -- i.e. how far neighbours may drift apart before the single-buffered halo rows of
-DESIGN.md section 9.1 would need a second buffer."""
+profiles/NOTES_r01_r04.md section 9.1 would need a second buffer."""
 import argparse
 import sys
 import time

@@ -1048,7 +1048,7 @@ template <typename T> static AmtMarchEntry<T> *amt_march_find(const AmtMarchShap
     return nullptr;
 }
 
-// Shape overrides: environment knobs, read once per process (DESIGN.md section 8b), or set at run
+// Shape overrides: environment knobs, read once per process (DESIGN.md section 9), or set at run
 // time through amt_march_force_shape -- tuning, A/B timing in one process and the parity tests
 // that walk every instantiation; 0 / -1 leave a parameter to the launcher.
 struct AmtMarchEnv {

@@ -116,7 +116,7 @@ program advance_mu_t_driver
   call up(AMT_F_MSFTX, c_loc(msftx)); call up(AMT_F_MSFTY, c_loc(msfty))
   call up(AMT_F_DNW, c_loc(dnw));   call up(AMT_F_FNM, c_loc(fnm));   call up(AMT_F_FNP, c_loc(fnp))
   call up(AMT_F_RDNW, c_loc(rdnw))
-  ! placement of the arrays' pages (+-3 % of a sweep, DESIGN.md section 4.2): sampled by the library, contents kept
+  ! placement of the arrays' pages (+-3 % of a sweep, DESIGN.md section 4.3): sampled by the library, contents kept
   if (ntune > 1) then
      call amt_check(amt_domain_tune_placement(dom, int(ntune, c_int), tune_ms), 'amt_domain_tune_placement')
      print '(a,i0,a,8f9.4)', 'placement tuning, ', ntune, ' allocations, ms/sweep each: ', tune_ms(1:ntune)
