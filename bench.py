@@ -1018,6 +1018,9 @@ def run_rank(a):
                                           else "gloo-host-staged (bring-up)") if world > 1 else None,
                        "ranks_share_a_device": bool(world > 1 and world > ndev),
                        "halo_pull": (stepper.pull_mode() or None) if native else None,
+                       "halo_schedule": (("host-waited: post, interior on its own, pull + boundary rows behind it" if os.environ.get("AMT_IPC_HOST_WAIT", "1") != "0"
+                                          else "device-waited: waiting kernel first, interior beside it") if native and a.transport == "ipc" and not a.no_overlap
+                                         else ("exchange beside the interior (2 rounds unless --beside-rounds)" if not a.no_overlap else "no overlap")) if world > 1 else None,
                        "interior_plan": {"beside_rounds": a.beside_rounds or 2, "beside_reserve_cus": a.beside_reserve} if world > 1 else None,
                        "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep(),
                        "placement_probe_ms": probe_ms,

@@ -328,6 +328,11 @@ int amt_synth_fill_device(void *hip_stream, int field, int dtype_bytes, void *ds
  *     the wire is busy -- RCCL's send/recv kernel holds 31) and posts "pulled"; a rank's sweep ends when its neighbours have
  *     pulled its rows.  The ranks must be processes of one node; they may share ONE device (how the two-rank tests run on
  *     a one-GPU box).  The arrays must come from hipMalloc or a pooled allocator over it (not hipMemMap ranges).
+ *     With overlap the IPC transport runs the HOST-WAITED schedule by default (AMT_IPC_HOST_WAIT=0: a waiting kernel instead): "rows
+ *     final" is posted on the domain's stream in front of the interior, amt_slab_step waits on the calling host thread until the
+ *     neighbours have posted theirs (so the call blocks for as long as a neighbour is behind -- per sub-step, like an MPI host),
+ *     and the pull and the boundary rows run behind an interior that had the whole chip: nothing holds a compute unit while a
+ *     neighbour is late (one rank of 8 in loopback: bare launch + 2.3 %, flat to 1.5 ms of lateness; profiles/r05_slab_ab.md).
  *     AMT_IPC_PULL=engine|kernel overrides how the rows are pulled (amt_slab_pull_mode; AMT_IPC_PULL_WGS: workgroups of the
  *     fused kernel, 4); AMT_IPC_TIMEOUT_S (120) bounds
  *     the host-side waits of the set-up, AMT_IPC_DEVICE_TIMEOUT_S (30) a device-side wait for a neighbour: it gives up,

@@ -56,22 +56,27 @@ def _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, world, dims, dtype,
             assert bits_equal(got, want.arrays[n][sb.jts - gb.jms: sb.jte + 1 - gb.jms]), f"rank {r}: {n} differs from the unsplit oracle run"
 
 
-@pytest.mark.parametrize("overlap,pull", [(True, "kernel"), (False, "kernel"), (True, "engine")],
-                         ids=["overlap-fused-kernel", "no-overlap-fused-kernel", "overlap-copy-engine"])
-def test_two_processes_on_one_device_at_4096x60x64_per_rank(pkg, oracle, tmp_path, overlap, pull):
-    """pull: ranks that share a device pull with the fused kernel by default; "engine" forces the path GPUs of a node take
-    (one hipMemcpyAsync per row from the peer mapping)."""
+@pytest.mark.parametrize("overlap,pull,host_wait", [(True, "kernel", "1"), (True, "kernel", "0"), (False, "kernel", "1"),
+                                                    (True, "engine", "1"), (True, "engine", "0")],
+                         ids=["host-waited-kernel-pull", "device-waited-fused-kernel", "no-overlap", "host-waited-copy-engine",
+                              "device-waited-copy-engine"])
+def test_two_processes_on_one_device_at_4096x60x64_per_rank(pkg, oracle, tmp_path, overlap, pull, host_wait):
+    """pull: ranks that share a device pull with a kernel by default; "engine" forces the path GPUs of a node take (one
+    hipMemcpyAsync per row from the peer mapping).  host_wait: the default schedule posts "rows final" on the domain's stream,
+    waits for the neighbours on the HOST and pulls behind a one-round interior; "0" is the device-side wait (a waiting kernel
+    enqueued before an interior planned in rounds)."""
     dims = (4096, 60, 128)
-    outs = _run_ranks(tmp_path, 2, dims, overlap=overlap, extra_env={"AMT_IPC_PULL": pull})
+    outs = _run_ranks(tmp_path, 2, dims, overlap=overlap, extra_env={"AMT_IPC_PULL": pull, "AMT_IPC_HOST_WAIT": host_wait})
     assert all("transport ipc, ranks seen 2" in o for o in outs), outs
-    assert all(("fused kernel" if pull == "kernel" else "copy engine") in o for o in outs), outs
+    assert all(("kernel" if pull == "kernel" else "copy engine") in o for o in outs), outs
     _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 2, dims, "f64", 2)
 
 
-def test_three_processes_uneven_rows_specified_boundaries_fp32(pkg, oracle, tmp_path):
+@pytest.mark.parametrize("host_wait", ["1", "0"], ids=["host-waited", "device-waited"])
+def test_three_processes_uneven_rows_specified_boundaries_fp32(pkg, oracle, tmp_path, host_wait):
     """The middle rank has both neighbours; 61 rows over 3 ranks; `specified` clips the outermost rows."""
     dims = (300, 24, 61)
-    _run_ranks(tmp_path, 3, dims, dtype="f32", sweeps=3, specified=True)
+    _run_ranks(tmp_path, 3, dims, dtype="f32", sweeps=3, specified=True, extra_env={"AMT_IPC_HOST_WAIT": host_wait})
     _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 3, dims, "f32", 3, specified=True)
 
 

@@ -92,10 +92,10 @@ def test_a_patch_without_its_halo_column_is_refused(pkg, torch_mod):
     assert e.value.status == lib.ERR_PRECONDITION and "halo column" in str(e.value)
 
 
-def _run_ranks(tmp_path, pi, pj, dims, *, dtype="f64", sweeps=2, overlap=True, specified=False, align=32):
+def _run_ranks(tmp_path, pi, pj, dims, *, dtype="f64", sweeps=2, overlap=True, specified=False, align=32, host_wait="1"):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(AMT_RENDEZVOUS_NONCE=f"grid-{tmp_path.name}", AMT_SLAB_TRANSPORT="ipc", AMT_IPC_DEVICE_TIMEOUT_S="20",
-               AMT_IPC_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               AMT_IPC_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0", AMT_IPC_HOST_WAIT=host_wait)
     procs = []
     for r in range(pi * pj):
         cmd = [sys.executable, str(WORKER), "--rank", str(r), "--grid", str(pi), str(pj), "--dir", str(tmp_path), "--dims",
@@ -130,10 +130,10 @@ def _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, pi, pj, dims, dtype
             assert bits_equal(got, want), f"rank {r} patch ({r % pi},{r // pi}): {n} differs from the unsplit oracle run"
 
 
-@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "no-overlap"])
-def test_2x2_processes_on_one_device_match_the_unsplit_oracle(pkg, oracle, tmp_path, overlap):
+@pytest.mark.parametrize("overlap,host_wait", [(True, "1"), (True, "0"), (False, "1")], ids=["host-waited", "device-waited", "no-overlap"])
+def test_2x2_processes_on_one_device_match_the_unsplit_oracle(pkg, oracle, tmp_path, overlap, host_wait):
     dims = (300, 24, 80)
-    outs = _run_ranks(tmp_path, 2, 2, dims, overlap=overlap, specified=True)
+    outs = _run_ranks(tmp_path, 2, 2, dims, overlap=overlap, specified=True, host_wait=host_wait)
     assert all("transport ipc, ranks seen 4" in o for o in outs), outs
     _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 2, 2, dims, "f64", 2, True, 32)
 

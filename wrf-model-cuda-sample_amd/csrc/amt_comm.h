@@ -29,6 +29,11 @@ int amt_exchange_create(AmtExchange **out, int transport, int rank, int world, c
 int amt_exchange_destroy(AmtExchange *x);
 // Phase A on `stream`: when it has run, every receive segment holds the sender's current rows.
 int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream);
+// The same phase for the IPC transport with the wait on the HOST instead of in a kernel (no compute unit is held while the
+// neighbour is late): post on the stream that made the rows final, poll on the calling thread, pull on `stream`.
+int amt_exchange_enqueue_post(AmtExchange *x, hipStream_t stream);
+int amt_exchange_host_wait(AmtExchange *x);
+int amt_exchange_enqueue_pull(AmtExchange *x, hipStream_t stream);
 // Phase B on `stream` (IPC; nothing for RCCL, whose sends complete inside the group): when it has run, every destination
 // has pulled this exchange's rows -- the send segments may be overwritten.
 int amt_exchange_enqueue_release(AmtExchange *x, hipStream_t stream);

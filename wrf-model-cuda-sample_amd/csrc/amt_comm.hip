@@ -394,6 +394,20 @@ struct AmtPullSegs {
     void *dst[kMaxExports];
     unsigned long long bytes[kMaxExports];
 };
+// The pull alone (host-waited exchange: the host has seen every source's "rows final" before this is enqueued): blockIdx.y =
+// segment, 16 bytes per lane.  It runs after the interior, with the chip to itself: many workgroups, a few microseconds.
+__global__ __launch_bounds__(256) void amt_xchg_pull(AmtPullSegs g)
+{
+    const size_t n16 = g.bytes[blockIdx.y] / 16;
+    const amt_v4u *src = static_cast<const amt_v4u *>(g.src[blockIdx.y]);
+    amt_v4u *dst = static_cast<amt_v4u *>(g.dst[blockIdx.y]);
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n16; e += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + e), dst + e);
+    const size_t tail0 = n16 * 16, tail = g.bytes[blockIdx.y] - tail0;
+    if (blockIdx.x == 0 && threadIdx.x < tail)
+        static_cast<unsigned char *>(g.dst[blockIdx.y])[tail0 + threadIdx.x] = static_cast<const unsigned char *>(g.src[blockIdx.y])[tail0 + threadIdx.x];
+}
+
 // The whole of phase A as ONE kernel (the default between ranks that share a device; AMT_IPC_PULL=kernel elsewhere): a march
 // workgroup takes a compute unit whole, so beside a slab's interior every kernel of the communication stream starts only where
 // an interior workgroup ends -- a chain of wait, six copies and post would queue at one such place after the other
@@ -776,6 +790,64 @@ int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream)
     for (size_t r = 0; r < x->recvs.size(); ++r)
         AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, hipMemcpyDeviceToDevice, stream));
     if (done.n) hipLaunchKernelGGL(amt_xchg_post, dim3(1), dim3(64), 0, stream, done, n);
+    AMT_HIP(hipGetLastError());
+    return AMT_OK;
+}
+
+// ---- the host-waited exchange (IPC): post on the domain's stream, wait on the HOST, pull behind the interior ------------------
+// Phase A in three parts, so that NOTHING of the exchange holds a compute unit while the interior runs (a march workgroup
+// takes a unit whole: a one-round interior has no unit to spare, profiles/r05_slab_ab.md):
+//   amt_exchange_enqueue_post   "my send segments are final for exchange n" -- one wave on the stream that produced them
+//   amt_exchange_host_wait      the calling HOST thread polls the mailbox until every source has posted n (or AMT_IPC_TIMEOUT_S)
+//   amt_exchange_enqueue_pull   the rows, then "pulled n" to the sources
+int amt_exchange_enqueue_post(AmtExchange *x, hipStream_t stream)
+{
+    if (!amt_exchange_active(x) || x->transport != AMT_XCHG_IPC) return amt_fail(AMT_ERR_INVALID_ARG, "the host-waited exchange needs the IPC transport");
+    const unsigned long long n = ++x->seq;
+    AmtDevPtrs mine{};
+    mine.p[mine.n++] = x->dev(&x->slot(x->rank)->ready);
+    hipLaunchKernelGGL(amt_xchg_post, dim3(1), dim3(64), 0, stream, mine, n);
+    AMT_HIP(hipGetLastError());
+    return AMT_OK;
+}
+
+int amt_exchange_host_wait(AmtExchange *x)
+{
+    if (!amt_exchange_active(x) || x->transport != AMT_XCHG_IPC) return AMT_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int p : x->sources) {
+        unsigned spins = 0;
+        while (__atomic_load_n(&x->slot(p)->ready, __ATOMIC_ACQUIRE) < x->seq) {
+            if (++spins > 4000) {
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > x->host_timeout)
+                    return amt_fail(AMT_ERR_COMM, "IPC halo exchange %llu: rank %d did not post its rows within %.0f s (AMT_IPC_TIMEOUT_S)",
+                                    x->seq, p, x->host_timeout);
+            }
+        }
+    }
+    if (x->skew_ticks) {                                  // test hook: the neighbours' rows are this late -- counted from the moment
+        // the last source posted (in loopback: from the start of this rank's own sweep on the device)
+        const auto late = std::chrono::steady_clock::now() + std::chrono::nanoseconds(x->skew_ticks * 10ull);
+        while (std::chrono::steady_clock::now() < late) { }
+    }
+    return AMT_OK;
+}
+
+int amt_exchange_enqueue_pull(AmtExchange *x, hipStream_t stream)
+{
+    if (!amt_exchange_active(x) || x->transport != AMT_XCHG_IPC) return AMT_OK;
+    if (x->pull_kernel && !x->recvs.empty()) {
+        AmtPullSegs g{};
+        for (size_t r = 0; r < x->recvs.size(); ++r) { g.src[r] = x->recv_src[r]; g.dst[r] = x->recvs[r].ptr; g.bytes[r] = x->recvs[r].bytes; }
+        hipLaunchKernelGGL(amt_xchg_pull, dim3(32, (unsigned)x->recvs.size()), dim3(256), 0, stream, g);
+    } else {
+        for (size_t r = 0; r < x->recvs.size(); ++r)
+            AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    AmtDevPtrs done{};
+    for (int p : x->sources) done.p[done.n++] = x->dev(&x->slot(p)->pulled[x->rank]);
+    if (done.n) hipLaunchKernelGGL(amt_xchg_post, dim3(1), dim3(64), 0, stream, done, x->seq);
     AMT_HIP(hipGetLastError());
     return AMT_OK;
 }

@@ -134,6 +134,29 @@ int grid_tile(amt_grid *g, hipStream_t stream, int its, int ite, int jts, int jt
     return beside_the_exchange ? amt_device_call_shared<T>(stream, g->dom->variant, a) : amt_device_call<T>(stream, g->dom->variant, a);
 }
 
+// the cells that read a neighbour's data, after the halos are in: boundary rows over the patch's whole width (they own the
+// corners), boundary columns over the rows in between; every tile is clipped on its own by the routine's window rule
+template <typename T>
+int grid_edges(amt_grid *g, hipStream_t edge_stream, bool lo, bool hi, bool lf, bool rt, bool unclipped, int in_jlo, int in_jhi)
+{
+    amt_domain *d = g->dom;
+    const int ilo = d->its, ihi = d->ite, jlo = d->jts, jhi = d->jte;
+    int rc = AMT_OK;
+    if (lo && hi && jhi > jlo && unclipped) {                           // both rows in one launch
+        AmtArgs<T> a;
+        amt_domain_args<T>(d, a);
+        a.jts = jlo; a.jte = jhi;
+        rc = amt_device_call_edges<T>(edge_stream, d->variant, a);
+        if (rc) return rc;
+    } else {                                                            // one-row tiles
+        if (lo) { rc = grid_tile<T>(g, edge_stream, ilo, ihi, jlo, jlo < jhi ? jlo : jhi); if (rc) return rc; }
+        if (hi && (jhi > jlo || !lo)) { rc = grid_tile<T>(g, edge_stream, ilo, ihi, jhi, jhi); if (rc) return rc; }
+    }
+    if (lf) { rc = grid_tile<T>(g, edge_stream, ilo, ilo < ihi ? ilo : ihi, in_jlo, in_jhi); if (rc) return rc; }
+    if (rt && (ihi > ilo || !lf)) { rc = grid_tile<T>(g, edge_stream, ihi, ihi, in_jlo, in_jhi); if (rc) return rc; }
+    return AMT_OK;
+}
+
 template <typename T>
 int grid_step_t(amt_grid *g, int n_sweeps)
 {
@@ -171,6 +194,33 @@ int grid_step_t(amt_grid *g, int n_sweeps)
         // transport the exchange therefore goes out FIRST: its waiting kernel has its compute unit(s) from the start of the
         // sweep and the rows are in as soon as the neighbour has them.  RCCL's send/recv kernel holds its units for as long as
         // it waits, so there the interior keeps its head start (AMT_SLAB_EXCHANGE_FIRST=0|1 overrides either).
+        // IPC transport with overlap: the HOST-WAITED schedule (default; AMT_IPC_HOST_WAIT=0 for the device-side wait below).
+        // Nothing of the exchange holds a compute unit while the interior runs, so the interior is planned on its own -- one
+        // round where it can be one, full efficiency -- and the neighbours' lateness hides behind ALL of it:
+        //   domain stream: [gather columns] -> post "rows final n" (one wave) -> interior
+        //   host:          poll the mailbox until every neighbour has posted n (the call returns after that: per sub-step, as
+        //                  a host that exchanges by MPI would wait)
+        //   comm stream:   pull (copy engine between GPUs; one kernel on a shared device) -> post "pulled n" -> [scatter columns]
+        //                  -> boundary rows / columns -> wait until the neighbours have pulled -> join
+        // The boundary tiles need compute units, which they get when the interior's workgroups end: they run right behind it.
+        static const bool host_wait_env = [] { const char *e = getenv("AMT_IPC_HOST_WAIT"); return !(e && *e && atoi(e) == 0); }();
+        if (g->overlap && host_wait_env && amt_exchange_transport(g->xchg) == AMT_XCHG_IPC && amt_exchange_active(g->xchg)) {
+            rc = grid_pack(g, d->stream);
+            if (rc == AMT_OK) rc = amt_exchange_enqueue_post(g->xchg, d->stream);
+            if (rc) return rc;
+            AMT_HIP(hipEventRecord(g->inputs_final, d->stream));
+            AMT_HIP(hipStreamWaitEvent(g->comm_stream, g->inputs_final, 0));
+            rc = grid_tile<T>(g, d->stream, in_ilo, in_ihi, in_jlo, in_jhi);       // on its own: the launcher's best plan
+            if (rc) { join(); return rc; }
+            rc = amt_exchange_host_wait(g->xchg);
+            if (rc == AMT_OK) rc = amt_exchange_enqueue_pull(g->xchg, g->comm_stream);
+            if (rc == AMT_OK) rc = grid_unpack(g, g->comm_stream);
+            if (rc == AMT_OK) rc = grid_edges<T>(g, g->comm_stream, lo, hi, lf, rt, unclipped, in_jlo, in_jhi);
+            if (rc == AMT_OK) rc = amt_exchange_enqueue_release(g->xchg, g->comm_stream);
+            join();
+            if (rc) return rc;
+            continue;
+        }
         static const int order_env = [] { const char *e = getenv("AMT_SLAB_EXCHANGE_FIRST"); return e && *e ? atoi(e) : -1; }();
         const bool exchange_first = order_env >= 0 ? order_env != 0 : amt_exchange_transport(g->xchg) == AMT_XCHG_IPC;
         auto interior_beside = [&]() { return grid_tile<T>(g, d->stream, in_ilo, in_ihi, in_jlo, in_jhi, true); };
@@ -206,20 +256,8 @@ int grid_step_t(amt_grid *g, int n_sweeps)
         }
         rc = grid_unpack(g, edge_stream);                                  // the columns that arrived, scattered into the halo
         if (rc) { join(); return rc; }
-        // boundary rows, over the patch's whole width (they own the corners)
-        if (lo && hi && jhi > jlo && unclipped) {                           // both in one launch
-            AmtArgs<T> a;
-            amt_domain_args<T>(d, a);
-            a.jts = jlo; a.jte = jhi;
-            rc = amt_device_call_edges<T>(edge_stream, d->variant, a);
-            if (rc) { join(); return rc; }
-        } else {                                                            // one-row tiles, each clipped on its own
-            if (lo) { rc = grid_tile<T>(g, edge_stream, ilo, ihi, jlo, jlo < jhi ? jlo : jhi); if (rc) { join(); return rc; } }
-            if (hi && (jhi > jlo || !lo)) { rc = grid_tile<T>(g, edge_stream, ilo, ihi, jhi, jhi); if (rc) { join(); return rc; } }
-        }
-        // boundary columns, over the rows in between
-        if (lf) { rc = grid_tile<T>(g, edge_stream, ilo, ilo < ihi ? ilo : ihi, in_jlo, in_jhi); if (rc) { join(); return rc; } }
-        if (rt && (ihi > ilo || !lf)) { rc = grid_tile<T>(g, edge_stream, ihi, ihi, in_jlo, in_jhi); if (rc) { join(); return rc; } }
+        rc = grid_edges<T>(g, edge_stream, lo, hi, lf, rt, unclipped, in_jlo, in_jhi);
+        if (rc) { join(); return rc; }
         // the sweep ends when the neighbours have this sweep's rows (RCCL: the sends of the group have completed; IPC: they
         // have pulled them) -- whatever the host model does to v, t_1, ... next cannot reach a neighbour's old read
         rc = amt_exchange_enqueue_release(g->xchg, edge_stream);
