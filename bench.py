@@ -1040,6 +1040,9 @@ def run_rank(a):
                          "aggregate_GBps": round(abytes / ev_per_step_s / 1e9, 1)},
             "verified_vs_oracle": verified,
         }
+        if world > 1 and native and a.transport == "rccl":
+            out["faster_alternative"] = ("--transport ipc: the RCCL-free transport with its host-waited schedule (one rank of 8 in loopback: bare "
+                                         "launch + 2.3 %, flat to 1.5 ms of neighbour lateness; RCCL + 6 % and half the lateness), profiles/r05_slab_ab.md")
         if world > 1 and world > ndev:
             out["note"] = (f"{world} ranks share {ndev} device(s): a correctness run of the whole N > 1 path (slabs, halo exchange, "
                            "verification, reductions); `value` is NOT a scaling measurement")
