@@ -148,3 +148,42 @@ def test_two_fortran_ranks_on_one_device_rendezvous_then_fail_cleanly(pkg, drive
         assert all("amt:" in o and ("ncclCommInitRank" in o or "RCCL" in o) for o in outs), outs
         slow_note("two Fortran ranks refused by RCCL", took, 200)
     assert not uid.exists() and not list(tmp_path.glob("uid.ack.*")), "the rendezvous leaves nothing behind"
+
+
+@pytest.mark.gpu
+def test_two_fortran_ranks_share_the_device_over_the_ipc_transport(pkg, oracle, drivers, tmp_path):
+    """The same two-process launch of advance_mu_t_slab_driver with AMT_SLAB_TRANSPORT=ipc in the environment -- no change to the
+    Fortran: both ranks run on the one device, the communicator reports two ranks, and each rank's sum(mu) over the rows it owns is
+    the unsplit oracle run's (2 warm-up + 3 timed sweeps)."""
+    import os
+    import re
+    exe = FDIR / "advance_mu_t_slab_driver_f64"
+    ni, nk, nj, sweeps = 256, 20, 64, 3
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, AMT_RENDEZVOUS_FILE=str(tmp_path / "uid"), AMT_RENDEZVOUS_NONCE="fortran-pair-ipc", RANK=str(rank),
+                   WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29556", AMT_SLAB_TRANSPORT="ipc", AMT_IPC_TIMEOUT_S="90",
+                   AMT_IPC_DEVICE_TIMEOUT_S="20", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([str(exe), str(ni), str(nk), str(nj), str(sweeps)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a Fortran rank hung: " + "".join(outs))
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert "2 rank(s) in the communicator" in outs[0], outs[0]
+    S = pkg.synth
+    gb = S.domain_bounds(ni, nk, nj)
+    full = S.make_patch(gb, pkg.GridConfig(), dtype=np.float64, seed=12345, global_dims=(ni, nk, nj))
+    for _ in range(2 + sweeps):
+        oracle.advance_mu_t(*full.args())
+    for rank, out in enumerate(outs):
+        m = re.search(r"rows (\d+)\.\.(\d+) .*sum\(mu\)\s+([-+0-9.eE]+)", out)
+        assert m, out
+        jlo, jhi = int(m.group(1)), int(m.group(2))
+        total = full.arrays["mu"][jlo - gb.jms: jhi - gb.jms + 1, 1 - gb.ims: 1 - gb.ims + ni].astype(np.float64).sum()
+        assert abs(float(m.group(3)) - total) <= 1e-9 * abs(total), (rank, m.group(3), total)
