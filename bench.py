@@ -939,6 +939,8 @@ def run_rank(a):
 
     def fence():
         torch.cuda.synchronize()
+        if native:
+            stepper.sync()                         # also reports a device-side wait for a neighbour that gave up (IPC transport)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()

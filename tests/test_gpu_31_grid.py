@@ -1,6 +1,6 @@
-"""i x j decomposition on a real GPU: four processes (2 x 2 patches) share cuda:0, the halos are
-staged through the host over gloo (RCCL refuses ranks that share a device) -- HIP kernels on padded
-patch memory, packed column halos, NaN-poisoned halo cells."""
+"""i x j decomposition on a real GPU through patch.GridStepper: four processes (2 x 2 patches) share cuda:0, NaN-poisoned halo
+cells.  Two paths behind the one class: the torch.distributed bring-up path (halos staged through the host over gloo) and the
+native one (GridStepper(native="ipc") forwards to the C++ runtime amt_grid_*: HIP pack / unpack kernels, IPC transport)."""
 import os
 import socket
 import sys
@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, pi, pj, sweeps, out_dir):
+def _worker(rank, world, port, shape, pi, pj, sweeps, out_dir, native=None):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -46,9 +46,17 @@ def _worker(rank, world, port, shape, pi, pj, sweeps, out_dir):
                 a[name][..., b.ite - b.ims + 1].fill_(nan)
         if ri > 0:
             a["t_1"][..., b.its - b.ims - 1].fill_(nan)
-        st = pkg.patch.GridStepper(dev, ri, rj, pi, pj, pkg.advance_mu_t, stage_through_host=True)
+        if native:
+            # GridStepper as a thin caller of the C++ runtime (amt_grid_*): the communicator id travels over the host group
+            uid = [pkg.patch.NativeGridStepper.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            st = pkg.patch.GridStepper(dev, ri, rj, pi, pj, pkg.advance_mu_t, native=native, unique_id=uid[0])
+        else:
+            st = pkg.patch.GridStepper(dev, ri, rj, pi, pj, pkg.advance_mu_t, stage_through_host=True)
         for _ in range(sweeps):
             st.step()
+        if native:
+            st._native.sync()
         torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), bounds=np.array(pb.as_tuple()),
                  **{n: a[n].cpu().numpy() for n in S.OUTPUTS})
@@ -56,9 +64,13 @@ def _worker(rank, world, port, shape, pi, pj, sweeps, out_dir):
         dist.destroy_process_group()
 
 
-def test_2x2_patches_on_one_gpu_match_the_oracle(tmp_path, pkg, oracle):
+@pytest.mark.parametrize("native", [None, "ipc"], ids=["torch-gloo-host-staged", "native-amt_grid-ipc"])
+def test_2x2_patches_on_one_gpu_match_the_oracle(tmp_path, pkg, oracle, native, monkeypatch):
     shape, pi, pj, sweeps = (150, 12, 40), 2, 2, 2
-    mp.spawn(_worker, args=(pi * pj, _free_port(), shape, pi, pj, sweeps, str(tmp_path)), nprocs=pi * pj, join=True)
+    if native:
+        monkeypatch.setenv("AMT_SLAB_TRANSPORT", "ipc")           # rank 0's id then needs no RCCL
+        monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_worker, args=(pi * pj, _free_port(), shape, pi, pj, sweeps, str(tmp_path), native), nprocs=pi * pj, join=True)
     S = pkg.synth
     full = S.make_patch(S.domain_bounds(*shape), pkg.GridConfig(specified=True), seed=17)
     for _ in range(sweeps):
