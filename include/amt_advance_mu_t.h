@@ -322,12 +322,13 @@ int amt_synth_fill_device(void *hip_stream, int field, int dtype_bytes, void *ds
  *     Two transports carry the rows.  RCCL (the default; loaded on first use with dlopen, AMT_RCCL_LIBRARY overrides the
  *     name): xGMI between the GPUs of a node; it needs one device per rank.  IPC (AMT_SLAB_TRANSPORT_IPC, or
  *     AMT_SLAB_TRANSPORT=ipc in the environment of a host that cannot pass the flag): no RCCL at all -- at creation the
- *     ranks trade hipIpcMemHandles of their boundary rows through a POSIX shared-memory block named after the unique id;
+ *     ranks trade hipIpcMemHandles of small staging buffers (copies of their boundary rows, refreshed by a kernel per sweep: the
+ *     caller's arrays may be of any size and from any allocator) through a POSIX shared-memory block named after the unique id;
  *     per sweep the receiver waits for its neighbour's "rows final" number in that block (a one-wave kernel), pulls the rows
  *     with the copy engine (hipMemcpyAsync from the peer mapping: SDMA over xGMI between GPUs, no compute unit held while
  *     the wire is busy -- RCCL's send/recv kernel holds 31) and posts "pulled"; a rank's sweep ends when its neighbours have
  *     pulled its rows.  The ranks must be processes of one node; they may share ONE device (how the two-rank tests run on
- *     a one-GPU box).  The arrays must come from hipMalloc or a pooled allocator over it (not hipMemMap ranges).
+ *     a one-GPU box).
  *     With overlap the IPC transport runs the HOST-WAITED schedule by default (AMT_IPC_HOST_WAIT=0: a waiting kernel instead): "rows
  *     final" is posted on the domain's stream in front of the interior, amt_slab_step waits on the calling host thread until the
  *     neighbours have posted theirs (so the call blocks for as long as a neighbour is behind -- per sub-step, like an MPI host),

@@ -320,8 +320,8 @@ constexpr int kMaxPeers = 4;             // below, above, left, right
 constexpr uint64_t kShmMagic = 0x414d54584348470aull;       // "AMTXCHG\n"
 
 struct ShmExport {
-    hipIpcMemHandle_t handle;            // of the ALLOCATION the segment lies in (hipMemGetAddressRange)
-    uint64_t offset;                     // of the segment inside it
+    hipIpcMemHandle_t handle;            // of the sender's staging buffer (one allocation per rank)
+    uint64_t offset;                     // of the segment's copy inside it
     uint64_t bytes;
     int32_t dest;
     int32_t pad;
@@ -477,6 +477,8 @@ struct AmtExchange {
     size_t shm_bytes = 0;
     bool shm_registered = false;
     char *shm_dev = nullptr;                 // the block as the device addresses it
+    void *stage = nullptr;                   // copies of the send segments: what the neighbours map and pull
+    std::vector<size_t> stage_off;
     std::vector<void *> opened;              // hipIpcOpenMemHandle mappings to close
     std::vector<const void *> recv_src;      // per receive segment: where to pull it from
     std::vector<int> sources, dests;         // distinct peer ranks
@@ -518,6 +520,15 @@ int amt_ipc_barrier(AmtExchange *x)
 int amt_ipc_setup(AmtExchange *x, const void *unique_id)
 {
     const int world = x->world, rank = x->rank;
+    // AMT_IPC_DEBUG=1: one stderr line per step of the set-up, with the seconds since it began (field diagnosis of a launch
+    // whose ranks do not find each other)
+    static const bool debug = [] { const char *e = getenv("AMT_IPC_DEBUG"); return e && *e && atoi(e) != 0; }();
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto trace = [&](const char *what) {
+        if (debug)
+            fprintf(stderr, "[amt ipc] rank %d/%d +%.3f s: %s\n", rank, world,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), what);
+    };
     if ((int)x->sends.size() > kMaxExports || (int)x->recvs.size() > kMaxExports)
         return amt_fail(AMT_ERR_INVALID_ARG, "more than %d segments per rank", kMaxExports);
     auto distinct = [](const std::vector<AmtSeg> &v) {
@@ -554,6 +565,7 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
     close(fd);
     if (m == MAP_FAILED) return amt_fail(AMT_ERR_COMM, "mmap(%s) failed: %s", name, strerror(errno));
     x->shm = m;
+    trace(name);
     struct Unlinker { const char *n; bool armed; ~Unlinker() { if (armed) (void)shm_unlink(n); } } unlinker{name, rank == 0};
     ShmHeader *h = x->hdr();
     h->world = (uint32_t)world;                  // every rank writes the same values into the zero-filled block
@@ -564,6 +576,7 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
     void *dptr = nullptr;
     AMT_HIP(hipHostGetDevicePointer(&dptr, m, 0));
     x->shm_dev = static_cast<char *>(dptr);
+    trace("block registered with the device");
 
     // publish my send segments
     ShmRank *me = x->slot(rank);
@@ -571,25 +584,35 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
     me->device = x->device;
     (void)hipDeviceGetPCIBusId(me->bus_id, (int)sizeof me->bus_id, x->device);
     me->nexports = (int32_t)x->sends.size();
+    // What a neighbour pulls is a STAGING buffer this exchange owns, not the caller's arrays: one small hipMalloc holds a copy
+    // of every send segment (a kernel refreshes it per exchange, 8 MB per slab interface: microseconds), and only ITS handle
+    // is traded.  The caller's arrays may then be anything a kernel can read -- hipMalloc of any size, a pooled allocator,
+    // hipMemMap ranges -- and what the neighbour maps is 8 MB, not a 4 GiB array (hipIpcOpenMemHandle of an allocation of
+    // 4 GiB or more never returned on this ROCm: both ranks sat in it, profiles/r05_slab_ab.md section 5).
+    size_t stage_bytes = 0;
+    x->stage_off.assign(x->sends.size(), 0);
+    for (size_t k = 0; k < x->sends.size(); ++k) {
+        x->stage_off[k] = stage_bytes;
+        stage_bytes += (x->sends[k].bytes + 255) / 256 * 256;
+    }
+    hipIpcMemHandle_t stage_handle{};
+    if (stage_bytes) {
+        hipError_t he = hipMalloc(&x->stage, stage_bytes);
+        if (he != hipSuccess) return amt_fail(AMT_ERR_ALLOC, "hipMalloc of the %zu-byte halo staging buffer failed: %s", stage_bytes, hipGetErrorString(he));
+        if (!x->self_loop) {
+            he = hipIpcGetMemHandle(&stage_handle, x->stage);
+            if (he != hipSuccess) return amt_fail(AMT_ERR_COMM, "hipIpcGetMemHandle of the halo staging buffer failed: %s", hipGetErrorString(he));
+        }
+    }
     for (size_t k = 0; k < x->sends.size(); ++k) {
         ShmExport &e = me->exports[k];
         e.dest = x->sends[k].peer;
         e.bytes = x->sends[k].bytes;
-        e.offset = 0;
-        if (x->self_loop) continue;               // the rank's own pointers serve: nothing to open
-        void *base = nullptr;
-        size_t size = 0;
-        // the handle is of the whole allocation (a handle taken from an inner address opens at the base as well:
-        // profiles/r05_ipc_probe.txt), the offset travels beside it
-        AMT_HIP(hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, x->sends[k].ptr));
-        e.offset = (uint64_t)(static_cast<char *>(x->sends[k].ptr) - static_cast<char *>(base));
-        if (e.offset + e.bytes > size) return amt_fail(AMT_ERR_INVALID_ARG, "send segment %zu leaves its allocation", k);
-        hipError_t he = hipIpcGetMemHandle(&e.handle, base);
-        if (he != hipSuccess)
-            return amt_fail(AMT_ERR_COMM, "hipIpcGetMemHandle failed for send segment %zu: %s (arrays from hipMalloc or a pooled "
-                                          "allocator can be shared; virtual-memory (hipMemMap) ranges cannot)", k, hipGetErrorString(he));
+        e.offset = x->stage_off[k];
+        e.handle = stage_handle;
     }
     me->published.store(1, std::memory_order_release);
+    trace("send segments published");
 
     // open what I receive: the k-th receive from p is the k-th segment p sends to me
     const auto t0 = std::chrono::steady_clock::now();
@@ -616,10 +639,8 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
             if (e.bytes != x->recvs[r].bytes)
                 return amt_fail(AMT_ERR_COMM, "segment sizes differ between rank %d (%llu bytes) and rank %d (%zu bytes)", p,
                                 (unsigned long long)e.bytes, rank, x->recvs[r].bytes);
-            if (x->self_loop) {
-                int seen_s = 0;
-                for (const AmtSeg &s : x->sends)
-                    if (s.peer == rank && seen_s++ == kth) { x->recv_src[r] = s.ptr; break; }
+            if (x->self_loop) {                       // the rank's own staging buffer serves: nothing to open
+                x->recv_src[r] = static_cast<char *>(x->stage) + e.offset;
                 continue;
             }
             const std::string key(reinterpret_cast<const char *>(&e.handle), sizeof e.handle);
@@ -633,6 +654,7 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
                                     getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "unset");
                 x->opened.push_back(q);
                 it = mapped.emplace(key, q).first;
+                trace("opened a peer allocation");
             }
             x->recv_src[r] = static_cast<char *>(it->second) + e.offset;
         }
@@ -651,6 +673,7 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
     AMT_HIP(hipMalloc((void **)&x->wg_done, sizeof(unsigned int)));
     AMT_HIP(hipMemset(x->wg_done, 0, sizeof(unsigned int)));
     // everybody attached: the name can go (the mappings stay)
+    trace("attached; waiting for the others");
     h->attached.fetch_add(1, std::memory_order_acq_rel);
     while (h->attached.load(std::memory_order_acquire) < (uint32_t)world) {
         if (waited() > x->host_timeout)
@@ -685,6 +708,7 @@ int amt_exchange_destroy(AmtExchange *x)
     if (x->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);
     if (x->red) (void)hipFree(x->red);
     if (x->wg_done) (void)hipFree(x->wg_done);
+    if (x->stage) (void)hipFree(x->stage);
     for (void *q : x->opened) (void)hipIpcCloseMemHandle(q);
     if (x->shm_registered) (void)hipHostUnregister(x->shm);
     if (x->shm) (void)munmap(x->shm, x->shm_bytes);
@@ -766,10 +790,26 @@ void amt_exchange_bytes(const AmtExchange *x, size_t *sent, size_t *received)
     for (const AmtSeg &s : x->recvs) *received += s.bytes;
 }
 
+// IPC: refresh the staging copies of the send segments (the stream must be one on which the segments are final)
+static int amt_ipc_stage(AmtExchange *x, hipStream_t stream)
+{
+    if (x->sends.empty()) return AMT_OK;
+    AmtPullSegs g{};
+    for (size_t k = 0; k < x->sends.size(); ++k) {
+        g.src[k] = x->sends[k].ptr;
+        g.dst[k] = static_cast<char *>(x->stage) + x->stage_off[k];
+        g.bytes[k] = x->sends[k].bytes;
+    }
+    hipLaunchKernelGGL(amt_xchg_pull, dim3(16, (unsigned)x->sends.size()), dim3(256), 0, stream, g);
+    AMT_HIP(hipGetLastError());
+    return AMT_OK;
+}
+
 int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream)
 {
     if (!amt_exchange_active(x)) return AMT_OK;
     if (x->transport == AMT_XCHG_RCCL) return amt_rccl_exchange(x, stream);
+    if (int rc = amt_ipc_stage(x, stream)) return rc;
     const unsigned long long n = ++x->seq;
     ShmRank *me = x->slot(x->rank);
     AmtDevPtrs src{}, done{};
@@ -803,6 +843,7 @@ int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream)
 int amt_exchange_enqueue_post(AmtExchange *x, hipStream_t stream)
 {
     if (!amt_exchange_active(x) || x->transport != AMT_XCHG_IPC) return amt_fail(AMT_ERR_INVALID_ARG, "the host-waited exchange needs the IPC transport");
+    if (int rc = amt_ipc_stage(x, stream)) return rc;
     const unsigned long long n = ++x->seq;
     AmtDevPtrs mine{};
     mine.p[mine.n++] = x->dev(&x->slot(x->rank)->ready);
