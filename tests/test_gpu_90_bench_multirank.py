@@ -86,6 +86,19 @@ def test_configs3_at_its_full_size_as_eight_real_ranks_on_the_one_device():
     assert "NOT a scaling measurement" in out["note"]
 
 
+def test_two_ranks_of_the_full_domain_share_the_device_arrays_beyond_4_gib():
+    """Regression (r05): with two ranks of 4096 x 60 x 4096 fp64 every 3-D array is 4.16 GiB; trading IPC handles of such
+    allocations never returned from hipIpcOpenMemHandle.  The transport trades one small staging buffer per rank instead."""
+    import torch
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 110 * 2**30:
+        pytest.skip(f"needs about 90 GB of device memory, {free / 2**30:.0f} GB free")
+    out = _run(["--gpus", "2", "--share-gpu", "--transport", "ipc", "--steps", "3", "--warmup", "2", "--no-box-probe",
+                "--probe-placements", "1", "--comm-timeout", "90", "--launch-timeout", "500"], timeout=700)
+    assert out["ranks_seen"] == 2 and out["verified_vs_oracle"] is True and out["config"]["halo_transport"] == "ipc"
+    assert out["config"]["halo_schedule"].startswith("host-waited")
+
+
 def test_native_stepper_with_two_real_ranks():
     if _gpus() < 2:
         pytest.skip("RCCL needs one GPU per rank: fewer than two devices visible")
