@@ -29,7 +29,8 @@
  *    buffers of a tile in the CU's 160 KB of LDS, which ends at 240 levels in fp64 and
  *    264 in fp32 (16-column tiles; a fifth level per lane does not fit).  Beyond that
  *    AMT_VARIANT_AUTO falls back to the column kernel, which is correct but re-reads its
- *    neighbours and runs about 8x slower (9 % against 57-70 % of the HBM roofline).
+ *    neighbours and runs about 8x slower (9 % against 57-70 % of the HBM roofline); the first such call of a process says so
+ *    on stderr (AMT_QUIET=1 suppresses it).
  *  - Return value: AMT_OK or an amt_status code; nothing ever calls exit()
  *    (the reference's wrapper prints and exit(1)s, advance_mu_t_no_async.cu:22-32,
  *    82-85).  amt_last_error() gives the text for the calling thread.

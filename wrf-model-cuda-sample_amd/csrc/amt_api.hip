@@ -4,6 +4,7 @@
 // host drop-in is amt_oneshot.hip, the resident handle amt_domain.hip, the RCCL slab stepper
 // amt_slab.hip.  There is deliberately no CPU compute path anywhere.
 #include "amt_internal.h"
+#include <atomic>
 
 template <typename T> hipError_t amt_launch_column(hipStream_t, const AmtParams<T> &);
 template <typename T> hipError_t amt_launch_march(hipStream_t, const AmtParams<T> &);
@@ -126,8 +127,17 @@ int amt_build_params(const AmtArgs<T> &a, AmtParams<T> &p, AmtWindow &w, bool *e
 template <typename T>
 static int amt_launch(hipStream_t stream, int variant, const AmtParams<T> &p)
 {
-    if (variant == AMT_VARIANT_AUTO)
+    if (variant == AMT_VARIANT_AUTO) {
         variant = amt_march_supported(p) ? AMT_VARIANT_MARCH : AMT_VARIANT_COLUMN;
+        if (variant == AMT_VARIANT_COLUMN && p.nk > (sizeof(T) == 8 ? 240 : 264)) {
+            // the speed cliff of the header (beyond 240 levels in fp64 / 264 in fp32 the march kernel's tile no longer fits the LDS):
+            // said once per process on stderr, never silently (AMT_QUIET=1 to suppress)
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true) && !getenv("AMT_QUIET"))
+                fprintf(stderr, "amt: advance_mu_t with %d levels runs on the column kernel (about 8x slower than the march kernel, which "
+                                "holds at most 240 levels in fp64 / 264 in fp32); see include/amt_advance_mu_t.h, \"SPEED CLIFF\"\n", p.nk);
+        }
+    }
     hipError_t e;
     if (variant == AMT_VARIANT_COLUMN) {
         if ((size_t)p.nk * 64 * sizeof(T) > 160 * 1024)
