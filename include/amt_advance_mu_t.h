@@ -401,6 +401,8 @@ int amt_slab_max(amt_slab *slab, double *x);
  *      the domain's stream beside the exchange; the boundary rows (over the patch's whole width: they own the corners) and the
  *      boundary columns (over the rows in between) follow it on the communication stream.  amt_slab_* is the pi = 1 case of the
  *      same stepper.  Flags are enum amt_slab_flags (AMT_SLAB_LOOPBACK: the rank is its own neighbour on all four sides).
+ *      Cost on one patch (profiles/r05_grid_loopback.md): overlap +8 % at 2048 x 2048 columns, +20 % at 1024 x 1024 (three boundary
+ *      launches per sweep); AMT_SLAB_NO_OVERLAP (halos, then ONE launch) +3 % and +7 % plus the neighbours' lateness.
  * ------------------------------------------------------------------------ */
 typedef struct amt_grid amt_grid;
 int amt_grid_create(amt_grid **out, amt_domain *domain, int ri, int rj, int pi, int pj,

@@ -28,7 +28,8 @@ int amt_exchange_create(AmtExchange **out, int transport, int rank, int world, c
                         const AmtSeg *sends, int nsend, const AmtSeg *recvs, int nrecv, bool self_loop);
 int amt_exchange_destroy(AmtExchange *x);
 // Phase A on `stream`: when it has run, every receive segment holds the sender's current rows.
-int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream);
+// alone: nothing else of this rank runs meanwhile (no-overlap schedules): the IPC pull may take the whole chip
+int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream, bool alone = false);
 // The same phase for the IPC transport with the wait on the HOST instead of in a kernel (no compute unit is held while the
 // neighbour is late): post on the stream that made the rows final, poll on the calling thread, pull on `stream`.
 int amt_exchange_enqueue_post(AmtExchange *x, hipStream_t stream);

@@ -805,7 +805,7 @@ static int amt_ipc_stage(AmtExchange *x, hipStream_t stream)
     return AMT_OK;
 }
 
-int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream)
+int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream, bool alone)
 {
     if (!amt_exchange_active(x)) return AMT_OK;
     if (x->transport == AMT_XCHG_RCCL) return amt_rccl_exchange(x, stream);
@@ -822,7 +822,8 @@ int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream)
         a.err = x->dev(&me->error); a.wg_done = x->wg_done;
         a.nseg = (int)x->recvs.size();
         for (size_t r = 0; r < x->recvs.size(); ++r) { a.segs.src[r] = x->recv_src[r]; a.segs.dst[r] = x->recvs[r].ptr; a.segs.bytes[r] = x->recvs[r].bytes; }
-        hipLaunchKernelGGL(amt_xchg_fused, dim3((unsigned)x->pull_wgs), dim3(512), 0, stream, a);
+        // beside an interior every workgroup of this kernel holds a compute unit while it waits: few; alone on the chip: many
+        hipLaunchKernelGGL(amt_xchg_fused, dim3((unsigned)(alone ? 64 : x->pull_wgs)), dim3(512), 0, stream, a);
         AMT_HIP(hipGetLastError());
         return AMT_OK;
     }

@@ -21,6 +21,8 @@ struct amt_grid {
     bool overlap = true;
     AmtExchange *xchg = nullptr;
     hipStream_t comm_stream = nullptr;
+    hipStream_t col_stream[2] = {nullptr, nullptr};         // the two boundary columns run beside the boundary rows
+    hipEvent_t halos_in = nullptr, col_done[2] = {nullptr, nullptr};
     hipEvent_t inputs_final = nullptr, edges_done = nullptr, t0 = nullptr, t1 = nullptr;
     int skew_us = 0;                                        // test hook: the neighbours' rows arrive this late
     // packed columns: what goes to the left / right neighbour, what came from the right / left one
@@ -123,12 +125,18 @@ __global__ void amt_grid_delay_kernel(unsigned long long ticks)
 }
 
 template <typename T>
-int grid_tile(amt_grid *g, hipStream_t stream, int its, int ite, int jts, int jte, bool beside_the_exchange = false)
+int grid_tile(amt_grid *g, hipStream_t stream, int its, int ite, int jts, int jte, bool beside_the_exchange = false, bool thin_column = false)
 {
     if (jte < jts || ite < its) return AMT_OK;
     AmtArgs<T> a;
     amt_domain_args<T>(g->dom, a);
     a.its = its; a.ite = ite; a.jts = jts; a.jte = jte;
+    // A boundary COLUMN is one column wide: the march kernel streams a whole tile for it; the column kernel -- one lane per
+    // column, the same bits -- would touch one line per element instead.
+    // Measured: the column kernel is the SLOWER one here (2048^2 patch: +18 % against +8.6 % per sweep, one active lane per
+    // workgroup walking its levels in sequence): off unless AMT_GRID_THIN_COLUMNS=1.
+    static const bool thin_env = [] { const char *e = getenv("AMT_GRID_THIN_COLUMNS"); return e && *e && atoi(e) != 0; }();
+    if (thin_column && thin_env && g->dom->variant == AMT_VARIANT_AUTO) return amt_device_call<T>(stream, AMT_VARIANT_COLUMN, a);
     // A launch that is ONE round of workgroups (the launcher's choice for a patch on its own) holds every compute unit
     // until it ends; beside the exchange the interior is planned as amt_march_set_beside says (profiles/r05_slab_ab.md).
     return beside_the_exchange ? amt_device_call_shared<T>(stream, g->dom->variant, a) : amt_device_call<T>(stream, g->dom->variant, a);
@@ -142,19 +150,33 @@ int grid_edges(amt_grid *g, hipStream_t edge_stream, bool lo, bool hi, bool lf, 
     amt_domain *d = g->dom;
     const int ilo = d->its, ihi = d->ite, jlo = d->jts, jhi = d->jte;
     int rc = AMT_OK;
-    if (lo && hi && jhi > jlo && unclipped) {                           // both rows in one launch
-        AmtArgs<T> a;
-        amt_domain_args<T>(d, a);
-        a.jts = jlo; a.jte = jhi;
-        rc = amt_device_call_edges<T>(edge_stream, d->variant, a);
-        if (rc) return rc;
-    } else {                                                            // one-row tiles
-        if (lo) { rc = grid_tile<T>(g, edge_stream, ilo, ihi, jlo, jlo < jhi ? jlo : jhi); if (rc) return rc; }
-        if (hi && (jhi > jlo || !lo)) { rc = grid_tile<T>(g, edge_stream, ilo, ihi, jhi, jhi); if (rc) return rc; }
+    // The boundary columns are independent of the rows and of each other: they go to streams of their own (three small
+    // launches, the chip has room for all of them at once) behind the event "halos are in", and join the edge stream.
+    const bool fork = (lf || rt) && g->col_stream[0] && edge_stream == g->comm_stream;
+    if (fork) AMT_HIP(hipEventRecord(g->halos_in, edge_stream));
+    int used = 0;
+    auto column = [&](int c) -> int {
+        hipStream_t st = fork ? g->col_stream[used] : edge_stream;
+        if (fork) AMT_HIP(hipStreamWaitEvent(st, g->halos_in, 0));
+        const int rc2 = grid_tile<T>(g, st, c, c, in_jlo, in_jhi, false, true);
+        if (fork) (void)hipEventRecord(g->col_done[used++], st);
+        return rc2;
+    };
+    if (lf) rc = column(ilo < ihi ? ilo : ihi);
+    if (rc == AMT_OK && rt && (ihi > ilo || !lf)) rc = column(ihi);
+    if (rc == AMT_OK) {
+        if (lo && hi && jhi > jlo && unclipped) {                       // both rows in one launch
+            AmtArgs<T> a;
+            amt_domain_args<T>(d, a);
+            a.jts = jlo; a.jte = jhi;
+            rc = amt_device_call_edges<T>(edge_stream, d->variant, a);
+        } else {                                                        // one-row tiles
+            if (lo) rc = grid_tile<T>(g, edge_stream, ilo, ihi, jlo, jlo < jhi ? jlo : jhi);
+            if (rc == AMT_OK && hi && (jhi > jlo || !lo)) rc = grid_tile<T>(g, edge_stream, ilo, ihi, jhi, jhi);
+        }
     }
-    if (lf) { rc = grid_tile<T>(g, edge_stream, ilo, ilo < ihi ? ilo : ihi, in_jlo, in_jhi); if (rc) return rc; }
-    if (rt && (ihi > ilo || !lf)) { rc = grid_tile<T>(g, edge_stream, ihi, ihi, in_jlo, in_jhi); if (rc) return rc; }
-    return AMT_OK;
+    for (int q = 0; q < used; ++q) (void)hipStreamWaitEvent(edge_stream, g->col_done[q], 0);      // always joined, also after an error
+    return rc;
 }
 
 template <typename T>
@@ -221,6 +243,18 @@ int grid_step_t(amt_grid *g, int n_sweeps)
             if (rc) return rc;
             continue;
         }
+        if (!g->overlap) {
+            // no overlap: the halos first, then the WHOLE patch as one launch (nothing to split when nothing runs beside)
+            rc = grid_pack(g, d->stream);
+            if (rc == AMT_OK && g->skew_us > 0 && !amt_exchange_owns_skew(g->xchg))
+                hipLaunchKernelGGL(amt_grid_delay_kernel, dim3(1), dim3(1), 16, d->stream, (unsigned long long)g->skew_us * 100ull);
+            if (rc == AMT_OK) rc = amt_exchange_enqueue(g->xchg, d->stream, true);
+            if (rc == AMT_OK) rc = grid_unpack(g, d->stream);
+            if (rc == AMT_OK) rc = grid_tile<T>(g, d->stream, ilo, ihi, jlo, jhi);
+            if (rc == AMT_OK) rc = amt_exchange_enqueue_release(g->xchg, d->stream);
+            if (rc) return rc;
+            continue;
+        }
         static const int order_env = [] { const char *e = getenv("AMT_SLAB_EXCHANGE_FIRST"); return e && *e ? atoi(e) : -1; }();
         const bool exchange_first = order_env >= 0 ? order_env != 0 : amt_exchange_transport(g->xchg) == AMT_XCHG_IPC;
         auto interior_beside = [&]() { return grid_tile<T>(g, d->stream, in_ilo, in_ihi, in_jlo, in_jhi, true); };
@@ -276,7 +310,9 @@ void grid_teardown(amt_grid *g)
     if (g->comm_stream) (void)hipStreamSynchronize(g->comm_stream);
     (void)amt_exchange_destroy(g->xchg);
     g->xchg = nullptr;
-    for (hipEvent_t e : {g->inputs_final, g->edges_done, g->t0, g->t1})
+    for (hipStream_t st : {g->col_stream[0], g->col_stream[1]})
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : {g->inputs_final, g->edges_done, g->t0, g->t1, g->halos_in, g->col_done[0], g->col_done[1]})
         if (e) (void)hipEventDestroy(e);
     if (g->comm_stream) (void)hipStreamDestroy(g->comm_stream);
     for (void *q : {g->to_left, g->to_right, g->from_right, g->from_left})
@@ -316,6 +352,12 @@ int grid_setup(amt_grid *g, amt_domain *dom, int ri, int rj, int pi, int pj, con
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&g->t0, &g->t1})
         if (e == hipSuccess) e = hipEventCreate(ev);
+    if (g->left >= 0 || g->right >= 0) {
+        for (hipStream_t *st : {&g->col_stream[0], &g->col_stream[1]})
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_high);
+        for (hipEvent_t *ev : {&g->halos_in, &g->col_done[0], &g->col_done[1]})
+            if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    }
     const ColumnPlan cp = column_plan(dom);
     if (e == hipSuccess && g->left >= 0) e = hipMalloc(&g->to_left, cp.bytes_from_right());
     if (e == hipSuccess && g->right >= 0) e = hipMalloc(&g->from_right, cp.bytes_from_right());
@@ -347,7 +389,7 @@ int grid_exchange_only(amt_grid *g)
     AMT_HIP(hipEventRecord(g->inputs_final, g->dom->stream));
     AMT_HIP(hipStreamWaitEvent(g->comm_stream, g->inputs_final, 0));
     int rc = grid_pack(g, g->comm_stream);
-    if (rc == AMT_OK) rc = amt_exchange_enqueue(g->xchg, g->comm_stream);
+    if (rc == AMT_OK) rc = amt_exchange_enqueue(g->xchg, g->comm_stream, true);
     if (rc == AMT_OK) rc = grid_unpack(g, g->comm_stream);
     if (rc == AMT_OK) rc = amt_exchange_enqueue_release(g->xchg, g->comm_stream);
     if (rc) return rc;
