@@ -86,6 +86,13 @@ def test_configs3_at_its_full_size_as_eight_real_ranks_on_the_one_device():
     assert "NOT a scaling measurement" in out["note"]
 
 
+def test_ipc_transport_under_the_torch_launcher():
+    """The driver's own N > 1 command line (python -m torch.distributed.run ... bench.py --gpus N) with the RCCL-free transport."""
+    out = _run(["--gpus", "2", "--share-gpu", "--transport", "ipc", "--probe-placements", "1", "--no-box-probe"] + SMALL, launcher=2)
+    assert out["launched_by"] == "external launcher" and out["ranks_seen"] == 2 and out["verified_vs_oracle"] is True
+    assert out["config"]["halo_transport"] == "ipc"
+
+
 def test_two_ranks_of_the_full_domain_share_the_device_arrays_beyond_4_gib():
     """Regression (r05): with two ranks of 4096 x 60 x 4096 fp64 every 3-D array is 4.16 GiB; trading IPC handles of such
     allocations never returned from hipIpcOpenMemHandle.  The transport trades one small staging buffer per rank instead."""
