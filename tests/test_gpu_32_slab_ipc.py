@@ -18,7 +18,7 @@ WORKER = ROOT / "tests" / "workers" / "slab_ipc_rank.py"
 pytestmark = pytest.mark.gpu
 
 
-def _run_ranks(tmp_path, world, dims, *, dtype="f64", sweeps=2, overlap=True, specified=False, extra_env=None, seed=11):
+def _run_ranks(tmp_path, world, dims, *, dtype="f64", sweeps=2, overlap=True, specified=False, extra_env=None, seed=11, jitter_us=0):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(AMT_RENDEZVOUS_NONCE=f"ipc-{tmp_path.name}", AMT_SLAB_TRANSPORT="ipc", AMT_IPC_DEVICE_TIMEOUT_S="20",
                AMT_IPC_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -29,6 +29,7 @@ def _run_ranks(tmp_path, world, dims, *, dtype="f64", sweeps=2, overlap=True, sp
                *map(str, dims), "--dtype", dtype, "--sweeps", str(sweeps), "--seed", str(seed)]
         cmd += [] if overlap else ["--no-overlap"]
         cmd += ["--specified"] if specified else []
+        cmd += ["--jitter-us", str(jitter_us)] if jitter_us else []
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -101,3 +102,14 @@ def test_a_missing_neighbour_ends_with_a_diagnosis_not_a_hang(pkg, tmp_path):
     quitter.wait(timeout=60)
     assert r.returncode != 0
     assert "did not publish" in r.stdout + r.stderr or "ranks attached" in r.stdout + r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("host_wait,pull", [("1", "kernel"), ("0", "kernel"), ("1", "engine")],
+                         ids=["host-waited", "device-waited", "host-waited-copy-engine"])
+def test_three_ranks_drifting_apart_for_150_sweeps(pkg, oracle, tmp_path, host_wait, pull):
+    """Stress of the mailbox protocol: three ranks, 150 single-sweep calls each with a random host sleep of up to 400 us in front
+    of every call, so that neighbours are early and late in turn while staging buffers are refreshed and pulled; the result after
+    150 sweeps is still the unsplit oracle run's, bit for bit (a stale or torn halo row would not wash out: t, mu, ww accumulate)."""
+    dims = (96, 12, 30)
+    _run_ranks(tmp_path, 3, dims, sweeps=150, jitter_us=400, extra_env={"AMT_IPC_HOST_WAIT": host_wait, "AMT_IPC_PULL": pull})
+    _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 3, dims, "f64", 150)

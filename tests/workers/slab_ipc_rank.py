@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--specified", action="store_true")
     ap.add_argument("--transport", default="ipc")
+    ap.add_argument("--jitter-us", type=int, default=0,
+                    help="stress: one sweep per call with a random host sleep of up to this many microseconds in front of each")
     a = ap.parse_args()
     import torch
     import __graft_entry__ as g
@@ -54,7 +56,15 @@ def main():
     try:
         assert st.transport() == a.transport, st.transport()
         seen = st.comm_info()
-        st.step(a.sweeps)
+        if a.jitter_us:
+            import random
+            import time
+            rng = random.Random(1000 + a.rank)
+            for _ in range(a.sweeps):               # ranks drift apart by up to the jitter every sweep, in both directions
+                time.sleep(rng.random() * a.jitter_us * 1e-6)
+                st.step(1)
+        else:
+            st.step(a.sweeps)
         st.sync()                                   # raises AmtError(ERR_COMM) if a device-side wait gave up
         for n in S.OUTPUTS:
             np.save(Path(a.dir) / f"out_{a.rank}_{n}.npy", dev.arrays[n][1:-1].cpu().numpy())
