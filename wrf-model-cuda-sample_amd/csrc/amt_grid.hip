@@ -195,59 +195,38 @@ int grid_step_t(amt_grid *g, int n_sweeps)
     const bool unclipped = wclip.j_start == jlo && wclip.j_end == jhi;
     // a failure between the fork (inputs_final) and the join (edges_done) must not leave the streams apart
     auto join = [&]() {
-        if (g->overlap) {
-            (void)hipEventRecord(g->edges_done, g->comm_stream);
-            (void)hipStreamWaitEvent(d->stream, g->edges_done, 0);
+        (void)hipEventRecord(g->edges_done, g->comm_stream);
+        (void)hipStreamWaitEvent(d->stream, g->edges_done, 0);
+    };
+    const bool none = !lo && !hi && !lf && !rt;
+    // cells that read a neighbour's data: rows jlo / jhi, columns ilo / ihi; the rest is interior
+    const int in_jlo = jlo + (lo ? 1 : 0), in_jhi = jhi - (hi ? 1 : 0);
+    const int in_ilo = ilo + (lf ? 1 : 0), in_ihi = ihi - (rt ? 1 : 0);
+    const bool ipc = amt_exchange_transport(g->xchg) == AMT_XCHG_IPC && amt_exchange_active(g->xchg);
+    static const bool host_wait_env = [] { const char *e = getenv("AMT_IPC_HOST_WAIT"); return !(e && *e && atoi(e) == 0); }();
+    static const int order_env = [] { const char *e = getenv("AMT_SLAB_EXCHANGE_FIRST"); return e && *e ? atoi(e) : -1; }();
+    auto delay_for_the_test_hook = [&](hipStream_t stream) {
+        if (g->skew_us <= 0 || amt_exchange_owns_skew(g->xchg)) return;
+        static const int wgs = [] { const char *e = getenv("AMT_SLAB_SKEW_WGS"); const int n = e ? atoi(e) : 1; return n > 1 ? n : 1; }();
+        if (wgs > 1) {
+            static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_grid_delay_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+            hipLaunchKernelGGL(amt_grid_delay_kernel, dim3(wgs), dim3(256), granted ? 96 * 1024 : 48 * 1024, stream, (unsigned long long)g->skew_us * 100ull);
+        } else {
+            hipLaunchKernelGGL(amt_grid_delay_kernel, dim3(1), dim3(1), 16, stream, (unsigned long long)g->skew_us * 100ull);
         }
     };
     for (int sweep = 0; sweep < n_sweeps; ++sweep) {
         int rc = AMT_OK;
-        if (!lo && !hi && !lf && !rt) {
+        if (none) {                                                        // a world of one: the plain launch
             rc = grid_tile<T>(g, d->stream, ilo, ihi, jlo, jhi);
             if (rc) return rc;
             continue;
         }
-        // cells that read a neighbour's data: rows jlo / jhi, columns ilo / ihi; the rest is interior
-        const int in_jlo = jlo + (lo ? 1 : 0), in_jhi = jhi - (hi ? 1 : 0);
-        const int in_ilo = ilo + (lf ? 1 : 0), in_ihi = ihi - (rt ? 1 : 0);
-        hipStream_t edge_stream = g->overlap ? g->comm_stream : d->stream;
-        // Order of the enqueues (profiles/r05_slab_ab.md).  A march workgroup takes a compute unit whole, so whatever the
-        // communication stream launches once the interior is out starts only where an interior workgroup ends.  With the IPC
-        // transport the exchange therefore goes out FIRST: its waiting kernel has its compute unit(s) from the start of the
-        // sweep and the rows are in as soon as the neighbour has them.  RCCL's send/recv kernel holds its units for as long as
-        // it waits, so there the interior keeps its head start (AMT_SLAB_EXCHANGE_FIRST=0|1 overrides either).
-        // IPC transport with overlap: the HOST-WAITED schedule (default; AMT_IPC_HOST_WAIT=0 for the device-side wait below).
-        // Nothing of the exchange holds a compute unit while the interior runs, so the interior is planned on its own -- one
-        // round where it can be one, full efficiency -- and the neighbours' lateness hides behind ALL of it:
-        //   domain stream: [gather columns] -> post "rows final n" (one wave) -> interior
-        //   host:          poll the mailbox until every neighbour has posted n (the call returns after that: per sub-step, as
-        //                  a host that exchanges by MPI would wait)
-        //   comm stream:   pull (copy engine between GPUs; one kernel on a shared device) -> post "pulled n" -> [scatter columns]
-        //                  -> boundary rows / columns -> wait until the neighbours have pulled -> join
-        // The boundary tiles need compute units, which they get when the interior's workgroups end: they run right behind it.
-        static const bool host_wait_env = [] { const char *e = getenv("AMT_IPC_HOST_WAIT"); return !(e && *e && atoi(e) == 0); }();
-        if (g->overlap && host_wait_env && amt_exchange_transport(g->xchg) == AMT_XCHG_IPC && amt_exchange_active(g->xchg)) {
-            rc = grid_pack(g, d->stream);
-            if (rc == AMT_OK) rc = amt_exchange_enqueue_post(g->xchg, d->stream);
-            if (rc) return rc;
-            AMT_HIP(hipEventRecord(g->inputs_final, d->stream));
-            AMT_HIP(hipStreamWaitEvent(g->comm_stream, g->inputs_final, 0));
-            rc = grid_tile<T>(g, d->stream, in_ilo, in_ihi, in_jlo, in_jhi);       // on its own: the launcher's best plan
-            if (rc) { join(); return rc; }
-            rc = amt_exchange_host_wait(g->xchg);
-            if (rc == AMT_OK) rc = amt_exchange_enqueue_pull(g->xchg, g->comm_stream);
-            if (rc == AMT_OK) rc = grid_unpack(g, g->comm_stream);
-            if (rc == AMT_OK) rc = grid_edges<T>(g, g->comm_stream, lo, hi, lf, rt, unclipped, in_jlo, in_jhi);
-            if (rc == AMT_OK) rc = amt_exchange_enqueue_release(g->xchg, g->comm_stream);
-            join();
-            if (rc) return rc;
-            continue;
-        }
         if (!g->overlap) {
-            // no overlap: the halos first, then the WHOLE patch as one launch (nothing to split when nothing runs beside)
+            // (1) NO OVERLAP: the halos first, then the WHOLE patch as one launch (nothing to split when nothing runs beside)
             rc = grid_pack(g, d->stream);
-            if (rc == AMT_OK && g->skew_us > 0 && !amt_exchange_owns_skew(g->xchg))
-                hipLaunchKernelGGL(amt_grid_delay_kernel, dim3(1), dim3(1), 16, d->stream, (unsigned long long)g->skew_us * 100ull);
+            if (rc == AMT_OK) delay_for_the_test_hook(d->stream);
             if (rc == AMT_OK) rc = amt_exchange_enqueue(g->xchg, d->stream, true);
             if (rc == AMT_OK) rc = grid_unpack(g, d->stream);
             if (rc == AMT_OK) rc = grid_tile<T>(g, d->stream, ilo, ihi, jlo, jhi);
@@ -255,51 +234,52 @@ int grid_step_t(amt_grid *g, int n_sweeps)
             if (rc) return rc;
             continue;
         }
-        static const int order_env = [] { const char *e = getenv("AMT_SLAB_EXCHANGE_FIRST"); return e && *e ? atoi(e) : -1; }();
-        const bool exchange_first = order_env >= 0 ? order_env != 0 : amt_exchange_transport(g->xchg) == AMT_XCHG_IPC;
-        auto interior_beside = [&]() { return grid_tile<T>(g, d->stream, in_ilo, in_ihi, in_jlo, in_jhi, true); };
-        if (g->overlap) {
-            AMT_HIP(hipEventRecord(g->inputs_final, d->stream));          // this sub-step's inputs are final
-            AMT_HIP(hipStreamWaitEvent(g->comm_stream, g->inputs_final, 0));
-            if (!exchange_first) {
-                rc = interior_beside();                                    // interior overlaps the exchange
-                if (rc) { join(); return rc; }
-            }
-        }
-        if (g->skew_us > 0 && !amt_exchange_owns_skew(g->xchg)) {
-            static const int wgs = [] { const char *e = getenv("AMT_SLAB_SKEW_WGS"); const int n = e ? atoi(e) : 1; return n > 1 ? n : 1; }();
-            if (wgs > 1) {
-                static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_grid_delay_kernel),
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-                hipLaunchKernelGGL(amt_grid_delay_kernel, dim3(wgs), dim3(256), granted ? 96 * 1024 : 48 * 1024, edge_stream,
-                                   (unsigned long long)g->skew_us * 100ull);
-            } else {
-                hipLaunchKernelGGL(amt_grid_delay_kernel, dim3(1), dim3(1), 16, edge_stream, (unsigned long long)g->skew_us * 100ull);
-            }
-        }
-        rc = grid_pack(g, edge_stream);                                    // the columns this patch sends, gathered
-        if (rc == AMT_OK) rc = amt_exchange_enqueue(g->xchg, edge_stream);
-        if (rc) { join(); return rc; }
-        if (g->overlap && exchange_first) {
-            rc = interior_beside();
-            if (rc) { join(); return rc; }
-        }
-        if (!g->overlap) {
-            rc = grid_tile<T>(g, d->stream, in_ilo, in_ihi, in_jlo, in_jhi);
+        if (ipc && host_wait_env) {
+            // (2) HOST-WAITED (IPC transport, default; AMT_IPC_HOST_WAIT=0 for (3)).  A march workgroup takes a compute unit whole,
+            // so nothing can run BESIDE the interior (profiles/r05_slab_ab.md): here nothing of the exchange holds a unit while
+            // the interior runs, the interior is planned on its own -- one round where it can be one, full efficiency -- and the
+            // neighbours' lateness hides behind ALL of it:
+            //   domain stream: [gather columns] -> refresh the staging copies -> post "rows final n" (one wave) -> interior
+            //   host:          poll the mailbox until every neighbour has posted n (the call returns after that: per sub-step,
+            //                  as a host that exchanges by MPI would wait)
+            //   comm stream:   pull (copy engine between GPUs; one kernel on a shared device) -> post "pulled n" -> [scatter
+            //                  columns] -> boundary rows / columns -> wait until the neighbours have pulled -> join
+            // The boundary tiles get their compute units when the interior's workgroups end: they run right behind it.
+            rc = grid_pack(g, d->stream);
+            if (rc == AMT_OK) rc = amt_exchange_enqueue_post(g->xchg, d->stream);
             if (rc) return rc;
+            if (hipEventRecord(g->inputs_final, d->stream) != hipSuccess || hipStreamWaitEvent(g->comm_stream, g->inputs_final, 0) != hipSuccess)
+                return amt_fail(AMT_ERR_HIP, "amt_grid_step: cannot fork the communication stream: %s", hipGetErrorString(hipGetLastError()));
+            rc = grid_tile<T>(g, d->stream, in_ilo, in_ihi, in_jlo, in_jhi);       // on its own: the launcher's best plan
+            if (rc == AMT_OK) rc = amt_exchange_host_wait(g->xchg);
+            if (rc == AMT_OK) rc = amt_exchange_enqueue_pull(g->xchg, g->comm_stream);
+            if (rc == AMT_OK) rc = grid_unpack(g, g->comm_stream);
+            if (rc == AMT_OK) rc = grid_edges<T>(g, g->comm_stream, lo, hi, lf, rt, unclipped, in_jlo, in_jhi);
+            if (rc == AMT_OK) rc = amt_exchange_enqueue_release(g->xchg, g->comm_stream);
+            join();                                                        // also after an error: the streams never stay apart
+            if (rc) return rc;
+            continue;
         }
-        rc = grid_unpack(g, edge_stream);                                  // the columns that arrived, scattered into the halo
-        if (rc) { join(); return rc; }
-        rc = grid_edges<T>(g, edge_stream, lo, hi, lf, rt, unclipped, in_jlo, in_jhi);
-        if (rc) { join(); return rc; }
+        // (3) DEVICE-WAITED (RCCL; IPC with AMT_IPC_HOST_WAIT=0): the exchange on the communication stream, the interior BESIDE it
+        // on the domain's stream, planned by amt_march_set_beside (rounds, reserved units).  Whatever the communication stream
+        // launches once the interior is out starts only where an interior workgroup ends; the IPC transport's waiting kernel
+        // therefore goes out FIRST (it has its units from the start of the sweep), RCCL's send/recv kernel -- which holds its
+        // units for as long as it waits -- after the interior (AMT_SLAB_EXCHANGE_FIRST=0|1 overrides either).
+        const bool exchange_first = order_env >= 0 ? order_env != 0 : ipc;
+        if (hipEventRecord(g->inputs_final, d->stream) != hipSuccess || hipStreamWaitEvent(g->comm_stream, g->inputs_final, 0) != hipSuccess)
+            return amt_fail(AMT_ERR_HIP, "amt_grid_step: cannot fork the communication stream: %s", hipGetErrorString(hipGetLastError()));
+        if (!exchange_first) rc = grid_tile<T>(g, d->stream, in_ilo, in_ihi, in_jlo, in_jhi, true);
+        if (rc == AMT_OK) delay_for_the_test_hook(g->comm_stream);
+        if (rc == AMT_OK) rc = grid_pack(g, g->comm_stream);               // the columns this patch sends, gathered
+        if (rc == AMT_OK) rc = amt_exchange_enqueue(g->xchg, g->comm_stream);
+        if (rc == AMT_OK && exchange_first) rc = grid_tile<T>(g, d->stream, in_ilo, in_ihi, in_jlo, in_jhi, true);
+        if (rc == AMT_OK) rc = grid_unpack(g, g->comm_stream);             // the columns that arrived, scattered into the halo
+        if (rc == AMT_OK) rc = grid_edges<T>(g, g->comm_stream, lo, hi, lf, rt, unclipped, in_jlo, in_jhi);
         // the sweep ends when the neighbours have this sweep's rows (RCCL: the sends of the group have completed; IPC: they
-        // have pulled them) -- whatever the host model does to v, t_1, ... next cannot reach a neighbour's old read
-        rc = amt_exchange_enqueue_release(g->xchg, edge_stream);
-        if (rc) { join(); return rc; }
-        if (g->overlap) {
-            AMT_HIP(hipEventRecord(g->edges_done, g->comm_stream));
-            AMT_HIP(hipStreamWaitEvent(d->stream, g->edges_done, 0));
-        }
+        // have pulled them)
+        if (rc == AMT_OK) rc = amt_exchange_enqueue_release(g->xchg, g->comm_stream);
+        join();
+        if (rc) return rc;
     }
     return AMT_OK;
 }
