@@ -452,6 +452,17 @@ __global__ __launch_bounds__(512) void amt_xchg_fused(AmtFusedArgs a)
     }
 }
 
+// Kind of the copy-engine pull.  Between GPUs the runtime moves a device-to-device copy with SDMA by itself.  On ONE device it
+// is a blit kernel, which needs a compute unit; hipMemcpyDeviceToDeviceNoCU ("without using compute units") forces the engine
+// there too -- measured on this pool (profiles/r05_slab_ab.md): the kernel trace then shows no copy kernel at all, but the six
+// 2 MiB copies of a slab interface take ~80 us each through the engine against 3 us as blit kernels, and the loopback sweep
+// is 8 % slower.  So: the plain kind, and AMT_IPC_ENGINE_NOCU=1 for whoever wants the engine by name.
+hipMemcpyKind amt_engine_copy_kind()
+{
+    static const bool nocu = [] { const char *e = getenv("AMT_IPC_ENGINE_NOCU"); return e && *e && atoi(e) != 0; }();
+    return nocu ? hipMemcpyDeviceToDeviceNoCU : hipMemcpyDeviceToDevice;
+}
+
 double amt_env_seconds(const char *name, double dflt)
 {
     const char *e = getenv(name);
@@ -829,7 +840,7 @@ int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream, bool alone)
     }
     hipLaunchKernelGGL(amt_xchg_post_and_wait, dim3(1), dim3(64), 0, stream, x->dev(&me->ready), src, n, x->ticks, x->skew_ticks, x->dev(&me->error));
     for (size_t r = 0; r < x->recvs.size(); ++r)
-        AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, hipMemcpyDeviceToDevice, stream));
+        AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, amt_engine_copy_kind(), stream));
     if (done.n) hipLaunchKernelGGL(amt_xchg_post, dim3(1), dim3(64), 0, stream, done, n);
     AMT_HIP(hipGetLastError());
     return AMT_OK;
@@ -885,7 +896,7 @@ int amt_exchange_enqueue_pull(AmtExchange *x, hipStream_t stream)
         hipLaunchKernelGGL(amt_xchg_pull, dim3(32, (unsigned)x->recvs.size()), dim3(256), 0, stream, g);
     } else {
         for (size_t r = 0; r < x->recvs.size(); ++r)
-            AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, hipMemcpyDeviceToDevice, stream));
+            AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, amt_engine_copy_kind(), stream));
     }
     AmtDevPtrs done{};
     for (int p : x->sources) done.p[done.n++] = x->dev(&x->slot(p)->pulled[x->rank]);
