@@ -274,6 +274,25 @@ int amt_domain_download_rows(amt_domain *d, int field, int j_lo, int j_hi, void 
 int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,
                               long gi0, long gk0, long gj0,
                               long gidim, long gkdim, long gjdim);
+/* The same for the fields whose bit is set in field_mask (bit f = enum amt_field f) only; asynchronous on the domain's
+ * stream.  With AMT_EXCHANGED_FIELDS and a seed that changes per sub-step this stands in for WRF's advance_uv, which
+ * rewrites u and v before every advance_mu_t call (the operands of module_small_step_em.f90:143-146, :241-245): the rows
+ * and columns a patch sends then differ from sweep to sweep, and only an exchange that delivers EVERY sweep gives the
+ * bits of the unsplit run.  (AMT_EXCHANGED_FIELDS names enum amt_field: include amt_synth.h where it is expanded.) */
+#define AMT_FIELD_BIT(f) (1ull << (f))
+#define AMT_EXCHANGED_FIELDS                                                                                   \
+    (AMT_FIELD_BIT(AMT_F_U) | AMT_FIELD_BIT(AMT_F_U_1) | AMT_FIELD_BIT(AMT_F_V) | AMT_FIELD_BIT(AMT_F_V_1) |   \
+     AMT_FIELD_BIT(AMT_F_T_1) | AMT_FIELD_BIT(AMT_F_MUU) | AMT_FIELD_BIT(AMT_F_MUV) | AMT_FIELD_BIT(AMT_F_MSFUY) | \
+     AMT_FIELD_BIT(AMT_F_MSFVX_INV))
+int amt_domain_fill_fields(amt_domain *d, uint64_t field_mask, uint64_t seed,
+                           long gi0, long gk0, long gj0,
+                           long gidim, long gkdim, long gjdim);
+/* Verification aid: overwrite with NaN exactly what the stencil reads from a neighbour on the given sides -- row jte+1 of
+ * v, v_1, t_1, muv, msfvx_inv (AMT_SIDE_ABOVE), row jts-1 of t_1 (AMT_SIDE_BELOW), column ite+1 of u, u_1, t_1, muu, msfuy
+ * (AMT_SIDE_RIGHT), column its-1 of t_1 (AMT_SIDE_LEFT); asynchronous on the domain's stream.  A sweep whose exchange
+ * does not deliver then computes NaN in its boundary cells. */
+enum amt_sides { AMT_SIDE_BELOW = 1, AMT_SIDE_ABOVE = 2, AMT_SIDE_LEFT = 4, AMT_SIDE_RIGHT = 8 };
+int amt_domain_poison_halos(amt_domain *d, int sides);
 /* enqueue n_sweeps calls of advance_mu_t over the patch's tile; asynchronous */
 int amt_domain_step(amt_domain *d, int n_sweeps);
 /* same, bracketed by HIP events on the domain's stream; returns after completion */
@@ -287,7 +306,12 @@ int amt_domain_step_timed(amt_domain *d, int n_sweeps, float *ms_total);
 int amt_domain_tune_placement(amt_domain *domain, int tries, float *ms_per_try);
 /* amt_domain_create does the same sampling by itself for states of 256 MiB and more (AMT_DOMAIN_PLACEMENT_TRIES allocations, default
  * 4; 0 or 1 = the first allocation as it comes; skipped where a second copy of the state does not fit): a host that creates its
- * handle once gets the sweep time bench.py prints.  Returns the number of allocations timed by the last sampling of this handle
+ * handle once gets the sweep time bench.py prints.  COST, paid once at creation: up to TWICE the state plus a spacer of up to
+ * 4 GiB resident for a moment, and 3 sweeps per allocation, timed with the AUTO kernel on the arrays as allocated (before
+ * amt_domain_set_variant / the first upload: the placement of pages does not depend on either).  One process samples per device
+ * at a time (advisory lock /tmp/amt_placement_<pci address>.lock); it is skipped altogether when the ranks of the launch
+ * outnumber the visible devices (LOCAL_WORLD_SIZE, else WORLD_SIZE, > device count: ranks that share a device would sample beside
+ * each other's sweeps and could starve each other's allocations).  Returns the number of allocations timed by the last sampling of this handle
  * (0: none) and their sweep times (ms; 0 for sets that were not tried). */
 int amt_domain_placement(const amt_domain *domain, float *ms_per_try, int cap);
 int amt_domain_sync(amt_domain *d);

@@ -89,7 +89,8 @@ def test_slab_driver_loopback_agrees_with_the_torch_path(pkg, drivers, tmp_path,
     import re
     exe = FDIR / ("advance_mu_t_slab_driver_f64" if itemsize == 8 else "advance_mu_t_slab_driver_f32")
     ni, nk, nj, sweeps = 200, 12, 20, 3
-    env = dict(__import__("os").environ, AMT_RENDEZVOUS_FILE=str(tmp_path / "uid"), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(__import__("os").environ, AMT_RENDEZVOUS_FILE=str(tmp_path / "uid"), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               AMT_SLAB_REFRESH="1")                              # new u, v, t_1 ... and re-poisoned halo rows before every sweep
     r = subprocess.run([str(exe), str(ni), str(nk), str(nj), str(sweeps), "1"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"halo bytes/sweep (\d+); sum\(mu\)\s+([-+0-9.Ee]+)", r.stdout)
@@ -99,10 +100,12 @@ def test_slab_driver_loopback_agrees_with_the_torch_path(pkg, drivers, tmp_path,
     b = S.domain_bounds(ni, nk, nj, aligned=True)
     want = S.make_patch(b, pkg.GridConfig(), dtype=dtype, seed=12345, device="cuda:0")
     a = want.arrays
-    for n in S.HALO_FROM_ABOVE:
-        a[n][-1].copy_(a[n][1])
-    a["t_1"][0].copy_(a["t_1"][-2])
-    for _ in range(2 + sweeps):                                   # the driver warms up with two sweeps
+    for sweep in range(2 + sweeps):                               # the driver warms up with two sweeps
+        if sweep:
+            S.refresh_exchanged_inputs(want, 12345, sweep)
+        for n in S.HALO_FROM_ABOVE:
+            a[n][-1].copy_(a[n][1])
+        a["t_1"][0].copy_(a["t_1"][-2])
         pkg.advance_mu_t(*want.args())
     torch.cuda.synchronize()
     mu = want.to_host().arrays["mu"]
@@ -154,7 +157,8 @@ def test_two_fortran_ranks_on_one_device_rendezvous_then_fail_cleanly(pkg, drive
 def test_two_fortran_ranks_share_the_device_over_the_ipc_transport(pkg, oracle, drivers, tmp_path):
     """The same two-process launch of advance_mu_t_slab_driver with AMT_SLAB_TRANSPORT=ipc in the environment -- no change to the
     Fortran: both ranks run on the one device, the communicator reports two ranks, and each rank's sum(mu) over the rows it owns is
-    the unsplit oracle run's (2 warm-up + 3 timed sweeps)."""
+    the unsplit oracle run's (2 warm-up + 3 timed sweeps, each with new values of the exchanged fields and re-poisoned halo rows:
+    AMT_SLAB_REFRESH=1; the bit-level check of a Fortran host is the grid driver's dump in test_gpu_33)."""
     import os
     import re
     exe = FDIR / "advance_mu_t_slab_driver_f64"
@@ -163,7 +167,7 @@ def test_two_fortran_ranks_share_the_device_over_the_ipc_transport(pkg, oracle, 
     for rank in (0, 1):
         env = dict(os.environ, AMT_RENDEZVOUS_FILE=str(tmp_path / "uid"), AMT_RENDEZVOUS_NONCE="fortran-pair-ipc", RANK=str(rank),
                    WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29556", AMT_SLAB_TRANSPORT="ipc", AMT_IPC_TIMEOUT_S="90",
-                   AMT_IPC_DEVICE_TIMEOUT_S="20", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   AMT_IPC_DEVICE_TIMEOUT_S="20", HSA_ENABLE_IPC_MODE_LEGACY="0", AMT_SLAB_REFRESH="1")
         procs.append(subprocess.Popen([str(exe), str(ni), str(nk), str(nj), str(sweeps)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -179,7 +183,9 @@ def test_two_fortran_ranks_share_the_device_over_the_ipc_transport(pkg, oracle, 
     S = pkg.synth
     gb = S.domain_bounds(ni, nk, nj)
     full = S.make_patch(gb, pkg.GridConfig(), dtype=np.float64, seed=12345, global_dims=(ni, nk, nj))
-    for _ in range(2 + sweeps):
+    for sweep in range(2 + sweeps):
+        if sweep:
+            S.refresh_exchanged_inputs(full, 12345, sweep)        # AMT_SLAB_REFRESH=1: every sweep has its own u, v, t_1 ...
         oracle.advance_mu_t(*full.args())
     for rank, out in enumerate(outs):
         m = re.search(r"rows (\d+)\.\.(\d+) .*sum\(mu\)\s+([-+0-9.eE]+)", out)

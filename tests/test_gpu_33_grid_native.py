@@ -13,9 +13,9 @@ import numpy as np
 import pytest
 
 from conftest import bits_equal
+from multirank import grid_mismatches, loopback_halos_by_hand, oracle_sweeps, run_grid_ranks
 
 ROOT = Path(__file__).resolve().parent.parent
-WORKER = ROOT / "tests" / "workers" / "grid_ipc_rank.py"
 pytestmark = pytest.mark.gpu
 
 
@@ -33,42 +33,29 @@ def torch_mod():
 def test_loopback_rows_and_packed_columns_against_the_oracle(pkg, oracle, torch_mod, dtype, overlap, transport):
     """The middle patch of 3 x 3.  After the exchange row jte+1 of v, v_1, t_1, muv, msfvx_inv holds the patch's own row jts,
     row jts-1 of t_1 its own row jte, column ite+1 of u, u_1, t_1, muu, msfuy its own column its, column its-1 of t_1 its own
-    column ite.  Expected: the oracle on host arrays with exactly those rows and columns copied by hand, three sweeps."""
+    column ite.  Expected: the oracle on host arrays with exactly those rows and columns copied by hand, three sweeps, each
+    with its own values of the exchanged fields (seed + sweep) and freshly poisoned halos on the device side."""
     S = pkg.synth
     gdims = (190, 14, 45)
     pb = S.patch_bounds(S.domain_bounds(*gdims), 1, 1, 3, 3, align_elems=32)
     cfg = pkg.GridConfig()
     dev = S.make_patch(pb, cfg, dtype=dtype, seed=41, global_dims=gdims, device="cuda:0")
     want = dev.to_host()
-    a, cf, cl = dev.arrays, pb.its - pb.ims, pb.ite - pb.ims
-    nan = float("nan")
-    for n in S.HALO_FROM_ABOVE:
-        a[n][-1].fill_(nan)
-    a["t_1"][0].fill_(nan)
-    for n in pkg.patch.HALO_FROM_RIGHT:
-        a[n][..., cl + 1].fill_(nan)
-    a["t_1"][..., cf - 1].fill_(nan)
+    cf, cl = pb.its - pb.ims, pb.ite - pb.ims
+    S.poison_halos(dev, 15)
     torch_mod.cuda.synchronize()
-    w = want.arrays
-    for n in S.HALO_FROM_ABOVE:
-        w[n][-1] = w[n][1]
-    w["t_1"][0] = w["t_1"][-2]
-    # the exchange moves rows first and columns in the same step: a column buffer holds the column as it was BEFORE this
-    # exchange's rows landed, i.e. its halo-row cells are the sender's old ones -- never read by the stencil (no diagonals);
-    # mirror that: columns from the pre-exchange arrays' owned rows only
-    for n in pkg.patch.HALO_FROM_RIGHT:
-        w[n][1:-1, ..., cl + 1] = w[n][1:-1, ..., cf]
-    w["t_1"][1:-1, ..., cf - 1] = w["t_1"][1:-1, ..., cl]
     st = pkg.patch.NativeGridStepper(dev, 0, 0, 1, 1, pkg.patch.NativeGridStepper.comm_unique_id(), loopback=True, overlap=overlap,
                                      transport=transport)
     try:
         assert st.transport() == transport and st.halo_bytes_per_sweep() > 0
-        st.step(3)
+        for sweep in range(3):                 # new u, v, t_1 ... and re-poisoned halos before every sweep but the first
+            if sweep:
+                st.next_substep_inputs(41, sweep)
+            st.step(1)
         st.sync()
     finally:
         st.close()
-    for _ in range(3):
-        oracle.advance_mu_t(*want.args())
+    oracle_sweeps(pkg, oracle, want, 41, 3, before_each=lambda p: loopback_halos_by_hand(pkg, p, columns=True))
     got = dev.to_host()
     own = (slice(1, -1), Ellipsis, slice(cf, cl + 1))
     for n in S.OUTPUTS:
@@ -96,22 +83,17 @@ def test_loopback_on_a_patch_whose_boundary_cells_are_clipped(pkg, oracle, torch
     dev = S.make_patch(pb, cfg, dtype=np.float64, seed=33, global_dims=gdims, device="cuda:0")
     want = dev.to_host()
     cf, cl = pb.its - pb.ims, pb.ite - pb.ims
-    w = want.arrays
-    for n in S.HALO_FROM_ABOVE:
-        w[n][-1] = w[n][1]
-    w["t_1"][0] = w["t_1"][-2]
-    for n in pkg.patch.HALO_FROM_RIGHT:
-        w[n][1:-1, ..., cl + 1] = w[n][1:-1, ..., cf]
-    w["t_1"][1:-1, ..., cf - 1] = w["t_1"][1:-1, ..., cl]
     st = pkg.patch.NativeGridStepper(dev, 0, 0, 1, 1, pkg.patch.NativeGridStepper.comm_unique_id(), loopback=True, overlap=overlap,
                                      transport=transport)
     try:
-        st.step(5)
+        for sweep in range(5):
+            if sweep:
+                st.next_substep_inputs(33, sweep)
+            st.step(1)
         st.sync()
     finally:
         st.close()
-    for _ in range(5):
-        oracle.advance_mu_t(*want.args())
+    oracle_sweeps(pkg, oracle, want, 33, 5, before_each=lambda p: loopback_halos_by_hand(pkg, p, columns=True))
     got = dev.to_host()
     own = (slice(1, -1), Ellipsis, slice(cf, cl + 1))
     for n in S.OUTPUTS:
@@ -130,57 +112,24 @@ def test_a_patch_without_its_halo_column_is_refused(pkg, torch_mod):
     assert e.value.status == lib.ERR_PRECONDITION and "halo column" in str(e.value)
 
 
-def _run_ranks(tmp_path, pi, pj, dims, *, dtype="f64", sweeps=2, overlap=True, specified=False, align=32, host_wait="1"):
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env.update(AMT_RENDEZVOUS_NONCE=f"grid-{tmp_path.name}", AMT_SLAB_TRANSPORT="ipc", AMT_IPC_DEVICE_TIMEOUT_S="20",
-               AMT_IPC_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0", AMT_IPC_HOST_WAIT=host_wait)
-    procs = []
-    for r in range(pi * pj):
-        cmd = [sys.executable, str(WORKER), "--rank", str(r), "--grid", str(pi), str(pj), "--dir", str(tmp_path), "--dims",
-               *map(str, dims), "--dtype", dtype, "--sweeps", str(sweeps), "--align", str(align)]
-        cmd += [] if overlap else ["--no-overlap"]
-        cmd += ["--specified"] if specified else []
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=420)[0])
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise AssertionError("a rank hung:\n" + "\n".join(outs))
-    assert [p.returncode for p in procs] == [0] * (pi * pj), "\n".join(outs)
-    return outs
-
-
 def _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, pi, pj, dims, dtype, sweeps, specified, align):
-    S = pkg.synth
-    np_dtype = np.float64 if dtype == "f64" else np.float32
-    gb = S.domain_bounds(*dims)
-    full = S.make_patch(gb, pkg.GridConfig(specified=specified), dtype=np_dtype, seed=17, global_dims=dims)
-    for _ in range(sweeps):
-        oracle.advance_mu_t(*full.args())
-    for r in range(pi * pj):
-        b = S.patch_bounds(gb, r % pi, r // pi, pi, pj, align_elems=align)
-        for n in S.OUTPUTS:
-            got = np.load(tmp_path / f"out_{r}_{n}.npy")
-            want = full.arrays[n][b.jts - gb.jms: b.jte - gb.jms + 1, ..., b.its - gb.ims: b.ite - gb.ims + 1]
-            assert bits_equal(got, want), f"rank {r} patch ({r % pi},{r // pi}): {n} differs from the unsplit oracle run"
+    bad = grid_mismatches(pkg, oracle, tmp_path, pi, pj, dims, dtype, sweeps, specified, align)
+    assert not bad, f"(rank, array) pairs that differ from the unsplit oracle run: {bad}"
 
 
 @pytest.mark.parametrize("overlap,host_wait", [(True, "1"), (True, "0"), (False, "1")], ids=["host-waited", "device-waited", "no-overlap"])
 def test_2x2_processes_on_one_device_match_the_unsplit_oracle(pkg, oracle, tmp_path, overlap, host_wait):
     dims = (300, 24, 80)
-    outs = _run_ranks(tmp_path, 2, 2, dims, overlap=overlap, specified=True, host_wait=host_wait)
+    outs = run_grid_ranks(tmp_path, 2, 2, dims, sweeps=3, overlap=overlap, specified=True, host_wait=host_wait)
     assert all("transport ipc, ranks seen 4" in o for o in outs), outs
-    _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 2, 2, dims, "f64", 2, True, 32)
+    _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 2, 2, dims, "f64", 3, True, 32)
 
 
 def test_3x2_processes_uneven_patches_fp32_unaligned_rows(pkg, oracle, tmp_path):
     """The middle column of patches has a neighbour on every side but one; 151 columns over 3, 37 rows over 2; WRF's own
     unpadded memory (ims = its-1)."""
     dims = (151, 20, 37)
-    _run_ranks(tmp_path, 3, 2, dims, dtype="f32", sweeps=3, align=1)
+    run_grid_ranks(tmp_path, 3, 2, dims, dtype="f32", sweeps=3, align=1)
     _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 3, 2, dims, "f32", 3, False, 1)
 
 
@@ -188,14 +137,15 @@ def test_3x2_processes_uneven_patches_fp32_unaligned_rows(pkg, oracle, tmp_path)
 def test_fortran_host_2x2_processes_over_the_ipc_transport(pkg, oracle, tmp_path, real):
     """The i x j decomposition from a FORTRAN host (fortran/advance_mu_t_grid_driver.f90: amt_domain_create, amt_grid_create,
     amt_grid_step through ISO_C_BINDING; VERDICT r04: "no Fortran/C host can use it"): four processes share cuda:0, every halo
-    row and column NaN-poisoned by the driver, its seven output arrays dumped and held against the UNSPLIT oracle run."""
+    row and column NaN-poisoned by the driver before EVERY sweep and the exchanged fields refilled per sweep (AMT_GRID_REFRESH=1:
+    amt_domain_fill_fields / amt_domain_poison_halos through ISO_C_BINDING), its seven output arrays dumped and held against the UNSPLIT oracle run."""
     exe = ROOT / "wrf-model-cuda-sample_amd" / "fortran" / f"advance_mu_t_grid_driver_{real}"
     if not exe.exists():
         pytest.skip("Fortran grid driver not built (no Fortran compiler)")
-    dims, pi, pj, sweeps = (150, 12, 40), 2, 2, 2
+    dims, pi, pj, sweeps = (150, 12, 40), 2, 2, 3
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(AMT_RENDEZVOUS_FILE=str(tmp_path / "uid"), AMT_RENDEZVOUS_NONCE=f"fgrid-{tmp_path.name}", AMT_SLAB_TRANSPORT="ipc",
-               AMT_GRID_POISON="1", AMT_GRID_DUMP_DIR=str(tmp_path), WORLD_SIZE=str(pi * pj), LOCAL_RANK="0", MASTER_PORT="29577",
+               AMT_GRID_POISON="1", AMT_GRID_REFRESH="1", AMT_GRID_DUMP_DIR=str(tmp_path), WORLD_SIZE=str(pi * pj), LOCAL_RANK="0", MASTER_PORT="29577",
                AMT_IPC_DEVICE_TIMEOUT_S="20", AMT_IPC_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([str(exe), *map(str, dims), str(sweeps), str(pi), str(pj)], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(pi * pj)]
@@ -212,8 +162,7 @@ def test_fortran_host_2x2_processes_over_the_ipc_transport(pkg, oracle, tmp_path
     S = pkg.synth
     dt = np.float64 if real == "f64" else np.float32
     full = S.make_patch(S.domain_bounds(*dims), pkg.GridConfig(), dtype=dt, seed=12345, global_dims=dims)
-    for _ in range(sweeps):
-        oracle.advance_mu_t(*full.args())
+    oracle_sweeps(pkg, oracle, full, 12345, sweeps)               # AMT_GRID_REFRESH=1: new exchanged inputs before sweeps 2, 3
     for r in range(pi * pj):
         ims, ime, kms, kme, jms, jme, ilo, ihi, jlo, jhi = map(int, (tmp_path / f"rank{r}_bounds.txt").read_text().split())
         idim, kdim, jdim = ime - ims + 1, kme - kms + 1, jme - jms + 1

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, flags, sweeps, out_dir):
+def _worker(rank, world, port, shape, flags, sweeps, out_dir, static=False):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,12 +37,6 @@ def _worker(rank, world, port, shape, flags, sweeps, out_dir):
         sb = S.slab_bounds(gb, rank, world)
         host = S.make_patch(sb, pkg.GridConfig(**flags), seed=77, global_dims=shape)
         arrays = {k: torch.from_numpy(v) for k, v in host.arrays.items()}
-        # poison the halo rows: only a correct exchange can make the result right
-        for name in S.HALO_FROM_ABOVE:
-            if rank < world - 1:
-                arrays[name][-1].fill_(float("nan"))
-        if rank > 0:
-            arrays["t_1"][0].fill_(float("nan"))
         patch = S.Patch(sb, host.config, arrays, host.rdx, host.rdy, host.dts, host.epssm, shape)
 
         def compute(*args):
@@ -50,7 +44,12 @@ def _worker(rank, world, port, shape, flags, sweeps, out_dir):
             oracle.advance_mu_t(*args)
 
         stepper = pkg.patch.SlabStepper(patch, rank, world, compute)
-        for _ in range(sweeps):
+        for sweep in range(sweeps):
+            if sweep and not static:                    # new u, v, t_1 ... every sweep: the stand-in for advance_uv
+                S.refresh_exchanged_inputs(patch, 77, sweep)
+            # poison the halo rows: only an exchange that delivers THIS sweep's rows can make the result right
+            if not (sweep and static):
+                S.poison_halos(patch, S.neighbour_sides(0, rank, 1, world))
             stepper.step()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), jms=sb.jms, jts=sb.jts, jte=sb.jte,
                  halo_bytes=stepper.halo_bytes_per_sweep(),
@@ -67,7 +66,7 @@ def _worker(rank, world, port, shape, flags, sweeps, out_dir):
     (8, (24, 5, 61), dict(specified=True)),  # the target N, uneven rows (7 and 8 per rank), clipped outermost rows
 ])
 def test_slabs_reproduce_the_unsplit_domain(tmp_path, world, shape, flags):
-    sweeps = 2
+    sweeps = 3
     mp.spawn(_worker, args=(world, _free_port(), shape, flags, sweeps, str(tmp_path)), nprocs=world, join=True)
 
     sys.path.insert(0, str(ROOT))
@@ -75,7 +74,9 @@ def test_slabs_reproduce_the_unsplit_domain(tmp_path, world, shape, flags):
     pkg, oracle = g.load_package(), g.load_oracle()
     S = pkg.synth
     full = S.make_patch(S.domain_bounds(*shape), pkg.GridConfig(**flags), seed=77)
-    for _ in range(sweeps):
+    for sweep in range(sweeps):
+        if sweep:
+            S.refresh_exchanged_inputs(full, 77, sweep)
         oracle.advance_mu_t(*full.args())
     total_halo = 0
     for rank in range(world):
@@ -119,25 +120,16 @@ def _grid_worker(rank, world, port, shape, flags, pi, pj, sweeps, out_dir):
         pb = S.patch_bounds(S.domain_bounds(*shape), ri, rj, pi, pj)
         host = S.make_patch(pb, pkg.GridConfig(**flags), seed=91, global_dims=shape)
         arrays = {k: torch.from_numpy(v) for k, v in host.arrays.items()}
-        nan = float("nan")
-        b = pb
-        if rj < pj - 1:
-            for name in S.HALO_FROM_ABOVE:
-                arrays[name][-1].fill_(nan)
-        if rj > 0:
-            arrays["t_1"][0].fill_(nan)
-        if ri < pi - 1:
-            for name in pkg.patch.HALO_FROM_RIGHT:
-                arrays[name][..., b.ite - b.ims + 1].fill_(nan)
-        if ri > 0:
-            arrays["t_1"][..., b.its - b.ims - 1].fill_(nan)
         patch = S.Patch(pb, host.config, arrays, host.rdx, host.rdy, host.dts, host.epssm, shape)
 
         def compute(*args):
             oracle.advance_mu_t(*[a.numpy() if isinstance(a, torch.Tensor) else a for a in args])
 
         st = pkg.patch.GridStepper(patch, ri, rj, pi, pj, compute)
-        for _ in range(sweeps):
+        for sweep in range(sweeps):
+            if sweep:
+                S.refresh_exchanged_inputs(patch, 91, sweep)
+            S.poison_halos(patch, S.neighbour_sides(ri, rj, pi, pj))
             st.step()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), bounds=np.array(pb.as_tuple()),
                  **{n: arrays[n].numpy() for n in S.OUTPUTS})
@@ -153,14 +145,16 @@ def _grid_worker(rank, world, port, shape, flags, pi, pj, sweeps, out_dir):
 ])
 def test_2d_patches_reproduce_the_unsplit_domain(tmp_path, pi, pj, shape, flags):
     """i x j decomposition: packed column halos + row halos, NaN-poisoned."""
-    sweeps, world = 2, pi * pj
+    sweeps, world = 3, pi * pj
     mp.spawn(_grid_worker, args=(world, _free_port(), shape, flags, pi, pj, sweeps, str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, str(ROOT))
     import __graft_entry__ as g
     pkg, oracle = g.load_package(), g.load_oracle()
     S = pkg.synth
     full = S.make_patch(S.domain_bounds(*shape), pkg.GridConfig(**flags), seed=91)
-    for _ in range(sweeps):
+    for sweep in range(sweeps):
+        if sweep:
+            S.refresh_exchanged_inputs(full, 91, sweep)
         oracle.advance_mu_t(*full.args())
     for rank in range(world):
         r = np.load(tmp_path / f"rank{rank}.npz")
@@ -169,3 +163,44 @@ def test_2d_patches_reproduce_the_unsplit_domain(tmp_path, pi, pj, shape, flags)
             mine = r[n][b.jts - b.jms: b.jte - b.jms + 1, ..., b.its - b.ims: b.ite - b.ims + 1]
             want = full.arrays[n][b.jts: b.jte + 1, ..., b.its: b.ite + 1]        # global ims = jms = 0
             assert np.array_equal(mine.view(np.uint8), want.view(np.uint8)), (rank, n)
+
+
+def _slab_run_differs(tmp_path, world, shape, sweeps, *, fault=None, static=False):
+    """Ranks whose owned rows differ from the unsplit oracle run after `sweeps` sweeps under AMT_TEST_FAULT=fault."""
+    old = os.environ.pop("AMT_TEST_FAULT", None)
+    if fault:
+        os.environ["AMT_TEST_FAULT"] = fault            # inherited by the spawned ranks
+    try:
+        mp.spawn(_worker, args=(world, _free_port(), shape, {}, sweeps, str(tmp_path), static), nprocs=world, join=True)
+    finally:
+        os.environ.pop("AMT_TEST_FAULT", None)
+        if old is not None:
+            os.environ["AMT_TEST_FAULT"] = old
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as g
+    pkg, oracle = g.load_package(), g.load_oracle()
+    S = pkg.synth
+    full = S.make_patch(S.domain_bounds(*shape), pkg.GridConfig(), seed=77)
+    for sweep in range(sweeps):
+        if sweep and not static:
+            S.refresh_exchanged_inputs(full, 77, sweep)
+        oracle.advance_mu_t(*full.args())
+    bad = set()
+    for rank in range(world):
+        r = np.load(tmp_path / f"rank{rank}.npz")
+        jms, jts, jte = int(r["jms"]), int(r["jts"]), int(r["jte"])
+        for n in S.OUTPUTS:
+            if not np.array_equal(r[n][jts - jms: jte - jms + 1].view(np.uint8), full.arrays[n][jts: jte + 1].view(np.uint8)):
+                bad.add(rank)
+    return bad
+
+
+def test_an_exchange_that_stops_delivering_turns_the_check_red(tmp_path):
+    """The sensitivity the per-sweep refresh buys: AMT_TEST_FAULT=skip_exchange@n makes every rank skip
+    its n-th exchange.  With inputs that change every sweep and re-poisoned halos all three ranks come out wrong; with static
+    inputs (halos poisoned once) the same fault is INVISIBLE -- the blind spot the old tests had."""
+    shape, sweeps = (18, 4, 9), 4
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir(); (tmp_path / "c").mkdir()
+    assert _slab_run_differs(tmp_path / "a", 3, shape, sweeps) == set()
+    assert _slab_run_differs(tmp_path / "b", 3, shape, sweeps, fault="skip_exchange@3") == {0, 1, 2}
+    assert _slab_run_differs(tmp_path / "c", 3, shape, sweeps, fault="skip_exchange@3", static=True) == set()

@@ -1,7 +1,8 @@
 """One rank of a pi x pj multi-process run on ONE device (tests/test_gpu_33_grid_native.py starts pi * pj of these): the
 native stepper amt_grid_* with the IPC halo transport -- HIP pack / unpack of the halo columns, rows in place.  The rank fills
-its patch from the generator, poisons every halo row and column it has a neighbour for with NaN, steps, and writes the cells
-it owns of every output to <dir>/out_<rank>_<name>.npy; the parent holds the unsplit oracle run."""
+its patch from the generator and poisons every halo row and column it has a neighbour for with NaN; per sweep it gives the fields
+that cross a patch boundary new values (seed + sweep, as advance_uv would), poisons the halos again and steps once; it writes the
+cells it owns of every output to <dir>/out_<rank>_<name>.npy; the parent holds the unsplit oracle run."""
 import argparse
 import ctypes
 import os
@@ -26,6 +27,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--specified", action="store_true")
     ap.add_argument("--align", type=int, default=32)
+    ap.add_argument("--static-inputs", action="store_true", help="the inputs of sweep 1 for every sweep (see slab_ipc_rank.py)")
     a = ap.parse_args()
     import torch
     import __graft_entry__ as g
@@ -43,22 +45,19 @@ def main():
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         dev = S.make_patch(pb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device="cuda:0")
-        arr, nan = dev.arrays, float("nan")
-        if rj < pj - 1:
-            for n in S.HALO_FROM_ABOVE:
-                arr[n][-1].fill_(nan)
-        if rj > 0:
-            arr["t_1"][0].fill_(nan)
-        if ri < pi - 1:
-            for n in pkg.patch.HALO_FROM_RIGHT:
-                arr[n][..., pb.ite - pb.ims + 1].fill_(nan)
-        if ri > 0:
-            arr["t_1"][..., pb.its - pb.ims - 1].fill_(nan)
+        arr = dev.arrays
+        S.poison_halos(dev, S.neighbour_sides(ri, rj, pi, pj))
     torch.cuda.synchronize()
     st = pkg.patch.NativeGridStepper(dev, ri, rj, pi, pj, bytes(uid), stream=stream, overlap=not a.no_overlap, transport="ipc")
     try:
         seen = st.comm_info()
-        st.step(a.sweeps)
+        if a.static_inputs:
+            st.step(a.sweeps)
+        else:
+            for sweep in range(a.sweeps):          # new u, v, t_1 ... every sweep (the stand-in for advance_uv), halos re-poisoned
+                if sweep:
+                    st.next_substep_inputs(a.seed, sweep)
+                st.step(1)
         st.sync()
         own = (slice(pb.jts - pb.jms, pb.jte - pb.jms + 1), Ellipsis, slice(pb.its - pb.ims, pb.ite - pb.ims + 1))
         for n in S.OUTPUTS:

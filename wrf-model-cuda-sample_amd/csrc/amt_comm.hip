@@ -389,6 +389,33 @@ __global__ void amt_xchg_wait(AmtDevPtrs src, unsigned long long n, unsigned lon
 }
 
 typedef unsigned int amt_v4u __attribute__((ext_vector_type(4)));
+// One segment, by the `nthreads` threads of which this is number `tid`: 16 bytes per lane where both ends are 16-byte aligned,
+// else 4 bytes per lane (a row of the caller's arrays is only element-aligned: fp32 rows of an odd element count start on every
+// 4-byte boundary), the byte tail by the first lanes.  fill = true: the destination gets all-ones bytes instead (NaN in fp32
+// and fp64): what a receive segment holds when its source never posted.
+__device__ inline void amt_copy_segment(const void *src_, void *dst_, unsigned long long bytes, size_t tid, size_t nthreads, bool fill = false)
+{
+    const unsigned char *src = static_cast<const unsigned char *>(src_);
+    unsigned char *dst = static_cast<unsigned char *>(dst_);
+    size_t done;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        const amt_v4u *s16 = reinterpret_cast<const amt_v4u *>(src);
+        amt_v4u *d16 = reinterpret_cast<amt_v4u *>(dst);
+        const amt_v4u ones = {~0u, ~0u, ~0u, ~0u};
+        for (size_t e = tid; e < n16; e += nthreads) __builtin_nontemporal_store(fill ? ones : __builtin_nontemporal_load(s16 + e), d16 + e);
+        done = n16 * 16;
+    } else if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0) {
+        const size_t n4 = bytes / 4;
+        const unsigned int *s4 = reinterpret_cast<const unsigned int *>(src);
+        unsigned int *d4 = reinterpret_cast<unsigned int *>(dst);
+        for (size_t e = tid; e < n4; e += nthreads) __builtin_nontemporal_store(fill ? ~0u : __builtin_nontemporal_load(s4 + e), d4 + e);
+        done = n4 * 4;
+    } else {
+        done = 0;
+    }
+    for (size_t e = done + tid; e < bytes; e += nthreads) dst[e] = fill ? (unsigned char)0xff : src[e];
+}
 struct AmtPullSegs {
     const void *src[kMaxExports];
     void *dst[kMaxExports];
@@ -398,14 +425,8 @@ struct AmtPullSegs {
 // segment, 16 bytes per lane.  It runs after the interior, with the chip to itself: many workgroups, a few microseconds.
 __global__ __launch_bounds__(256) void amt_xchg_pull(AmtPullSegs g)
 {
-    const size_t n16 = g.bytes[blockIdx.y] / 16;
-    const amt_v4u *src = static_cast<const amt_v4u *>(g.src[blockIdx.y]);
-    amt_v4u *dst = static_cast<amt_v4u *>(g.dst[blockIdx.y]);
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n16; e += (size_t)gridDim.x * blockDim.x)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + e), dst + e);
-    const size_t tail0 = n16 * 16, tail = g.bytes[blockIdx.y] - tail0;
-    if (blockIdx.x == 0 && threadIdx.x < tail)
-        static_cast<unsigned char *>(g.dst[blockIdx.y])[tail0 + threadIdx.x] = static_cast<const unsigned char *>(g.src[blockIdx.y])[tail0 + threadIdx.x];
+    amt_copy_segment(g.src[blockIdx.y], g.dst[blockIdx.y], g.bytes[blockIdx.y], blockIdx.x * (size_t)blockDim.x + threadIdx.x,
+                     (size_t)gridDim.x * blockDim.x);
 }
 
 // The whole of phase A as ONE kernel (the default between ranks that share a device; AMT_IPC_PULL=kernel elsewhere): a march
@@ -423,27 +444,29 @@ struct AmtFusedArgs {
 };
 __global__ __launch_bounds__(512) void amt_xchg_fused(AmtFusedArgs a)
 {
+    __shared__ int gave_up;
     if (threadIdx.x == 0) {
+        gave_up = 0;
         if (blockIdx.x == 0) __hip_atomic_store(a.ready_mine, a.n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long t0 = wall_clock64();
         for (int q = 0; q < a.src_ready.n; ++q)
             while (__hip_atomic_load(a.src_ready.p[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.n) {
-                if (wall_clock64() - t0 > a.ticks) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                if (wall_clock64() - t0 > a.ticks) {
+                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    gave_up = 1;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(4);
             }
         while (wall_clock64() - t0 < a.skew_ticks) __builtin_amdgcn_s_sleep(8);      // test hook: the neighbours' rows are this late
     }
     __syncthreads();
-    for (int g = 0; g < a.nseg; ++g) {
-        const size_t n16 = a.segs.bytes[g] / 16;
-        const amt_v4u *src = static_cast<const amt_v4u *>(a.segs.src[g]);
-        amt_v4u *dst = static_cast<amt_v4u *>(a.segs.dst[g]);
-        for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n16; e += (size_t)gridDim.x * blockDim.x)
-            __builtin_nontemporal_store(__builtin_nontemporal_load(src + e), dst + e);
-        const size_t tail0 = n16 * 16, tail = a.segs.bytes[g] - tail0;
-        if (blockIdx.x == 0 && threadIdx.x < tail)
-            static_cast<unsigned char *>(a.segs.dst[g])[tail0 + threadIdx.x] = static_cast<const unsigned char *>(a.segs.src[g])[tail0 + threadIdx.x];
-    }
+    // a source that never posted: its rows are not valid -- the receive segments get NaN (all-ones) instead of whatever the
+    // peer's buffer holds, so that the sweep's results are loudly wrong as well as reported (amt_exchange_check)
+    const bool poison = gave_up != 0;
+    for (int g = 0; g < a.nseg; ++g)
+        amt_copy_segment(a.segs.src[g], a.segs.dst[g], a.segs.bytes[g], blockIdx.x * (size_t)blockDim.x + threadIdx.x,
+                         (size_t)gridDim.x * blockDim.x, poison);
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(a.wg_done, 1u) == gridDim.x - 1) {              // the last workgroup to finish posts
@@ -472,7 +495,9 @@ double amt_env_seconds(const char *name, double dflt)
 }
 
 std::mutex g_xchg_mutex;
-std::map<uint64_t, unsigned> g_xchg_instances;      // unique id -> exchanges this process has created with it
+// (unique id, rank) -> exchanges that rank has created with the id.  Per RANK, not per process: ranks that live in one process
+// (threads) count separately and agree with ranks elsewhere; a create that fails does not advance it.
+std::map<std::pair<uint64_t, int>, unsigned> g_xchg_instances;
 }  // namespace
 
 struct AmtExchange {
@@ -494,6 +519,7 @@ struct AmtExchange {
     std::vector<const void *> recv_src;      // per receive segment: where to pull it from
     std::vector<int> sources, dests;         // distinct peer ranks
     unsigned long long seq = 0;              // exchanges enqueued so far
+    unsigned long long exchanges = 0;        // phase A starts of either transport (what AMT_TEST_FAULT counts)
     unsigned long long released = 0;
     bool pull_kernel = false;               // one fused kernel (wait + pull + post) instead of wait kernel, copy-engine pulls, post kernel
     bool same_device_peers = true;          // every source rank computes on this rank's device (ranks that share a GPU; loopback)
@@ -556,32 +582,65 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
     x->ticks = (unsigned long long)(amt_env_seconds("AMT_IPC_DEVICE_TIMEOUT_S", 30.0) * 1e8);     // 100 MHz wall clock
     if (const char *e = getenv("AMT_IPC_PULL_WGS")) { const int n = atoi(e); if (n >= 1 && n <= 64) x->pull_wgs = n; }
 
-    // the block: one name per (unique id, how many exchanges this process made with it before) -- every rank creates
-    // its exchanges in the same order, so the counters agree; whoever comes first creates it, rank 0 removes the name
-    // once every rank is attached
+    // the block: one name per (unique id, how many exchanges THIS RANK made with it before) -- every rank creates its
+    // exchanges in the same order, so the counters agree.  Whoever comes first creates it (O_EXCL), sizes it and writes the
+    // header, the magic word last; everybody else opens it, waits for the magic word and VALIDATES world and rank_bytes (two
+    // launches, or two builds, that meet in one name must not talk).  The name goes when every rank is attached -- every
+    // rank unlinks, the first one wins -- and on the creator's error paths; a create that fails does not advance the counter.
     uint64_t idh = amt_fnv1a(1469598103934665603ull, unique_id, AMT_UNIQUE_ID_BYTES);
     unsigned instance;
     {
         std::lock_guard<std::mutex> lk(g_xchg_mutex);
-        instance = g_xchg_instances[idh]++;
+        instance = g_xchg_instances[{idh, rank}];
     }
     char name[80];
     snprintf(name, sizeof name, "/amt_xchg_%016llx_%u", (unsigned long long)idh, instance);
     const size_t rank_bytes = (sizeof(ShmRank) + (size_t)world * sizeof(unsigned long long) + 63) / 64 * 64;
     x->shm_bytes = (sizeof(ShmHeader) + rank_bytes * world + 4095) / 4096 * 4096;
-    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    bool creator = true;
+    int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 && errno == EEXIST) {
+        creator = false;
+        fd = shm_open(name, O_RDWR, 0600);
+    }
     if (fd < 0) return amt_fail(AMT_ERR_COMM, "shm_open(%s) failed: %s", name, strerror(errno));
-    if (ftruncate(fd, (off_t)x->shm_bytes) != 0) { close(fd); return amt_fail(AMT_ERR_COMM, "ftruncate(%s) failed: %s", name, strerror(errno)); }
+    struct Unlinker { const char *n; bool armed; ~Unlinker() { if (armed) (void)shm_unlink(n); } } unlinker{name, creator};
+    const auto t_open = std::chrono::steady_clock::now();
+    auto opened_for = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count(); };
+    if (creator) {
+        if (ftruncate(fd, (off_t)x->shm_bytes) != 0) { close(fd); return amt_fail(AMT_ERR_COMM, "ftruncate(%s) failed: %s", name, strerror(errno)); }
+    } else {
+        struct stat sb;                          // the creator sizes the block before anything else
+        for (;;) {
+            if (fstat(fd, &sb) != 0) { close(fd); return amt_fail(AMT_ERR_COMM, "fstat(%s) failed: %s", name, strerror(errno)); }
+            if ((size_t)sb.st_size >= x->shm_bytes) break;
+            if (sb.st_size != 0 || opened_for() > x->host_timeout) {
+                close(fd);
+                return amt_fail(AMT_ERR_COMM, "%s holds %lld bytes, this rank expects %zu (another launch, or another build, under the same name?)",
+                                name, (long long)sb.st_size, x->shm_bytes);
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
     void *m = mmap(nullptr, x->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (m == MAP_FAILED) return amt_fail(AMT_ERR_COMM, "mmap(%s) failed: %s", name, strerror(errno));
     x->shm = m;
     trace(name);
-    struct Unlinker { const char *n; bool armed; ~Unlinker() { if (armed) (void)shm_unlink(n); } } unlinker{name, rank == 0};
     ShmHeader *h = x->hdr();
-    h->world = (uint32_t)world;                  // every rank writes the same values into the zero-filled block
-    h->rank_bytes = (uint32_t)rank_bytes;
-    h->magic = kShmMagic;
+    if (creator) {
+        h->world = (uint32_t)world;
+        h->rank_bytes = (uint32_t)rank_bytes;
+        __atomic_store_n(&h->magic, kShmMagic, __ATOMIC_RELEASE);
+    } else {
+        while (__atomic_load_n(&h->magic, __ATOMIC_ACQUIRE) != kShmMagic) {
+            if (opened_for() > x->host_timeout) return amt_fail(AMT_ERR_COMM, "%s was never initialised by the rank that created it (%.0f s)", name, x->host_timeout);
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (h->world != (uint32_t)world || h->rank_bytes != (uint32_t)rank_bytes)
+            return amt_fail(AMT_ERR_COMM, "%s was set up for %u ranks of %u bytes, this rank is one of %d with %zu (ranks of different launches or builds)",
+                            name, h->world, h->rank_bytes, world, rank_bytes);
+    }
     AMT_HIP(hipHostRegister(m, x->shm_bytes, hipHostRegisterMapped | hipHostRegisterPortable));
     x->shm_registered = true;
     void *dptr = nullptr;
@@ -595,6 +654,7 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
     me->device = x->device;
     (void)hipDeviceGetPCIBusId(me->bus_id, (int)sizeof me->bus_id, x->device);
     me->nexports = (int32_t)x->sends.size();
+    me->error = 0;
     // What a neighbour pulls is a STAGING buffer this exchange owns, not the caller's arrays: one small hipMalloc holds a copy
     // of every send segment (a kernel refreshes it per exchange, 8 MB per slab interface: microseconds), and only ITS handle
     // is traded.  The caller's arrays may then be anything a kernel can read -- hipMalloc of any size, a pooled allocator,
@@ -691,6 +751,12 @@ int amt_ipc_setup(AmtExchange *x, const void *unique_id)
             return amt_fail(AMT_ERR_COMM, "%u of %d ranks attached to %s within %.0f s", h->attached.load(), world, name, x->host_timeout);
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
+    (void)shm_unlink(name);                      // every rank: the first one removes the name, the mappings stay
+    unlinker.armed = false;
+    {
+        std::lock_guard<std::mutex> lk(g_xchg_mutex);
+        ++g_xchg_instances[{idh, rank}];         // only a set-up that succeeded counts
+    }
     return AMT_OK;
 }
 
@@ -699,6 +765,7 @@ int amt_rccl_exchange(AmtExchange *x, hipStream_t stream)
     // per pair of ranks the order of sends matches the order of receives on the other side.  A failing call must not
     // leave the group open (every later RCCL call of this thread would be queued into it, the communicator's destruction
     // included): remember the first error and always close the group.
+    if (amt_test_fault("skip_group", x->exchanges)) return AMT_OK;      // fault injection: every rank skips the same group
     ncclResult_t first = ncclSuccess;
     const char *what = "";
     auto note = [&](ncclResult_t r, const char *w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; what = w; } };
@@ -804,7 +871,7 @@ void amt_exchange_bytes(const AmtExchange *x, size_t *sent, size_t *received)
 // IPC: refresh the staging copies of the send segments (the stream must be one on which the segments are final)
 static int amt_ipc_stage(AmtExchange *x, hipStream_t stream)
 {
-    if (x->sends.empty()) return AMT_OK;
+    if (x->sends.empty() || amt_test_fault("skip_stage", x->exchanges)) return AMT_OK;
     AmtPullSegs g{};
     for (size_t k = 0; k < x->sends.size(); ++k) {
         g.src[k] = x->sends[k].ptr;
@@ -819,8 +886,10 @@ static int amt_ipc_stage(AmtExchange *x, hipStream_t stream)
 int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream, bool alone)
 {
     if (!amt_exchange_active(x)) return AMT_OK;
+    ++x->exchanges;
     if (x->transport == AMT_XCHG_RCCL) return amt_rccl_exchange(x, stream);
     if (int rc = amt_ipc_stage(x, stream)) return rc;
+    const bool no_pull = amt_test_fault("skip_pull", x->exchanges);
     const unsigned long long n = ++x->seq;
     ShmRank *me = x->slot(x->rank);
     AmtDevPtrs src{}, done{};
@@ -831,7 +900,7 @@ int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream, bool alone)
         a.ready_mine = x->dev(&me->ready); a.src_ready = src; a.pulled_dst = done;
         a.n = n; a.ticks = x->ticks; a.skew_ticks = x->skew_ticks;
         a.err = x->dev(&me->error); a.wg_done = x->wg_done;
-        a.nseg = (int)x->recvs.size();
+        a.nseg = no_pull ? 0 : (int)x->recvs.size();
         for (size_t r = 0; r < x->recvs.size(); ++r) { a.segs.src[r] = x->recv_src[r]; a.segs.dst[r] = x->recvs[r].ptr; a.segs.bytes[r] = x->recvs[r].bytes; }
         // beside an interior every workgroup of this kernel holds a compute unit while it waits: few; alone on the chip: many
         hipLaunchKernelGGL(amt_xchg_fused, dim3((unsigned)(alone ? 64 : x->pull_wgs)), dim3(512), 0, stream, a);
@@ -839,7 +908,7 @@ int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream, bool alone)
         return AMT_OK;
     }
     hipLaunchKernelGGL(amt_xchg_post_and_wait, dim3(1), dim3(64), 0, stream, x->dev(&me->ready), src, n, x->ticks, x->skew_ticks, x->dev(&me->error));
-    for (size_t r = 0; r < x->recvs.size(); ++r)
+    for (size_t r = 0; r < x->recvs.size() && !no_pull; ++r)
         AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, amt_engine_copy_kind(), stream));
     if (done.n) hipLaunchKernelGGL(amt_xchg_post, dim3(1), dim3(64), 0, stream, done, n);
     AMT_HIP(hipGetLastError());
@@ -855,6 +924,7 @@ int amt_exchange_enqueue(AmtExchange *x, hipStream_t stream, bool alone)
 int amt_exchange_enqueue_post(AmtExchange *x, hipStream_t stream)
 {
     if (!amt_exchange_active(x) || x->transport != AMT_XCHG_IPC) return amt_fail(AMT_ERR_INVALID_ARG, "the host-waited exchange needs the IPC transport");
+    ++x->exchanges;
     if (int rc = amt_ipc_stage(x, stream)) return rc;
     const unsigned long long n = ++x->seq;
     AmtDevPtrs mine{};
@@ -890,7 +960,9 @@ int amt_exchange_host_wait(AmtExchange *x)
 int amt_exchange_enqueue_pull(AmtExchange *x, hipStream_t stream)
 {
     if (!amt_exchange_active(x) || x->transport != AMT_XCHG_IPC) return AMT_OK;
-    if (x->pull_kernel && !x->recvs.empty()) {
+    if (amt_test_fault("skip_pull", x->exchanges)) {
+        // fault injection: nothing is pulled, the protocol goes on
+    } else if (x->pull_kernel && !x->recvs.empty()) {
         AmtPullSegs g{};
         for (size_t r = 0; r < x->recvs.size(); ++r) { g.src[r] = x->recv_src[r]; g.dst[r] = x->recvs[r].ptr; g.bytes[r] = x->recvs[r].bytes; }
         hipLaunchKernelGGL(amt_xchg_pull, dim3(32, (unsigned)x->recvs.size()), dim3(256), 0, stream, g);

@@ -1,6 +1,10 @@
 // amt_domain.hip -- the resident domain handle amt_domain_*: native owner of the 26 device arrays,
 // a stream and the scalars, for C / Fortran hosts that keep the state on the GPU across sub-steps.
 #include "amt_internal.h"
+#include <fcntl.h>
+#include <sys/file.h>
+#include <time.h>
+#include <unistd.h>
 
 extern "C" int amt_domain_destroy(amt_domain *d)
 {
@@ -65,6 +69,37 @@ static int amt_domain_make(amt_domain **out, int dtype_bytes,
 
 static int amt_domain_tune(amt_domain *d, int tries, float *ms_per_try, bool preserve);
 
+// Do the ranks of this launch outnumber the devices this process sees (two test ranks on a one-GPU box, AMT_SLAB_TRANSPORT=ipc
+// with --share-gpu)?  Then several of them would sample at the same time on one device: each holds twice its state plus the
+// spacer for a moment -- a peer's allocation may fail -- and times its sweeps beside the others': noise.  
+static bool amt_ranks_outnumber_devices(int ndev)
+{
+    const char *lw = getenv("LOCAL_WORLD_SIZE"), *w = getenv("WORLD_SIZE");
+    const long n = lw && *lw ? atol(lw) : w && *w ? atol(w) : 1;
+    return n > ndev;
+}
+
+// One sampler per device at a time, across processes: an advisory lock on a file named after the device's PCI address,
+// held for the duration of the sampling (processes that share a device without saying so in their environment).  Gives up
+// after 60 s and returns -1: the caller then takes its first allocation as it comes.
+static int amt_placement_lock(int device)
+{
+    char bus[32] = "unknown";
+    (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, device);
+    for (char *q = bus; *q; ++q)
+        if (*q == ':' || *q == '.' || *q == '/') *q = '_';
+    char path[96];
+    snprintf(path, sizeof path, "/tmp/amt_placement_%s.lock", bus);
+    const int fd = open(path, O_CREAT | O_RDWR, 0666);
+    if (fd < 0) return -1;
+    for (int waited_ms = 0; flock(fd, LOCK_EX | LOCK_NB) != 0; waited_ms += 20) {
+        if (waited_ms >= 60000) { close(fd); return -1; }
+        struct timespec ts = {0, 20 * 1000 * 1000};
+        nanosleep(&ts, nullptr);
+    }
+    return fd;
+}
+
 extern "C" int amt_domain_create(amt_domain **out, int dtype_bytes,
                                  int periodic_x, int specified, int nested,
                                  int ids, int ide, int jds, int jde, int kde,
@@ -87,14 +122,24 @@ extern "C" int amt_domain_create(amt_domain **out, int dtype_bytes,
     size_t state = 0;
     for (int f = 0; f < AMT_F_COUNT; ++f) state += d->count(f) * (size_t)dtype_bytes;
     size_t free_b = 0, total_b = 0;
-    if (tries > 1 && state >= ((size_t)256 << 20) && kts == 1 && kte == kde && hipMemGetInfo(&free_b, &total_b) == hipSuccess
-        && free_b > state + state / 16 + ((size_t)6 << 30)) {
-        float ms[16] = {};
-        if (amt_domain_tune(d, tries, ms, false) == AMT_OK) {
-            d->placement_tries = tries;
-            memcpy(d->placement_ms, ms, sizeof ms);
+    int ndev = 1;
+    (void)hipGetDeviceCount(&ndev);
+    if (tries > 1 && state >= ((size_t)256 << 20) && kts == 1 && kte == kde && !amt_ranks_outnumber_devices(ndev)) {
+        // not when the ranks of this launch share devices; one sampler per device at a time otherwise (the memory check is made
+        // with the lock held: the only other large allocations of a well-behaved node are other samplers')
+        const int lock_fd = amt_placement_lock(d->device);
+        if (lock_fd >= 0) {
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > state + state / 16 + ((size_t)6 << 30)) {
+                float ms[16] = {};
+                if (amt_domain_tune(d, tries, ms, false) == AMT_OK) {
+                    d->placement_tries = tries;
+                    memcpy(d->placement_ms, ms, sizeof ms);
+                }
+                (void)hipGetLastError();                          // a sampling that could not run costs nothing but itself
+            }
+            (void)flock(lock_fd, LOCK_UN);
+            close(lock_fd);
         }
-        (void)hipGetLastError();                                  // a sampling that could not run costs nothing but itself
     }
     return AMT_OK;
 }
@@ -190,6 +235,87 @@ extern "C" int amt_domain_fill_synthetic(amt_domain *d, uint64_t seed,
     return AMT_OK;
 }
 
+extern "C" int amt_domain_fill_fields(amt_domain *d, uint64_t field_mask, uint64_t seed,
+                                      long gi0, long gk0, long gj0,
+                                      long gidim, long gkdim, long gjdim)
+{
+    if (!d) return amt_fail(AMT_ERR_INVALID_ARG, "null domain");
+    if (field_mask >> AMT_F_COUNT) return amt_fail(AMT_ERR_INVALID_ARG, "field mask names a field beyond AMT_F_COUNT");
+    DeviceScope scope(d->device);
+    const long idim = d->ime - d->ims + 1, kdim = d->kme - d->kms + 1, jdim = d->jme - d->jms + 1;
+    for (int f = 0; f < AMT_F_COUNT; ++f) {
+        if (!(field_mask & AMT_FIELD_BIT(f))) continue;
+        int rc = amt_synth_fill_device(d->stream, f, d->dtype_bytes, d->field[f], seed,
+                                       idim, kdim, jdim, gi0, gk0, gj0, gidim, gkdim, gjdim);
+        if (rc) return rc;
+    }
+    return AMT_OK;
+}
+
+// NaN into up to twelve strided runs in one launch: job q = `count` elements from `base` at stride `stride` (a row of the
+// (i,k,j) layout: stride 1; a column: stride idim)
+namespace {
+template <typename W>
+struct AmtPoisonJobs {
+    W *base[12];
+    long count[12], stride[12];
+    W nan;
+    int n;
+};
+template <typename W>
+__global__ __launch_bounds__(256) void amt_poison_kernel(AmtPoisonJobs<W> jobs)
+{
+    const int q = blockIdx.y;
+    W *p = jobs.base[q];
+    const long n = jobs.count[q], stride = jobs.stride[q];
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) p[e * stride] = jobs.nan;
+}
+
+template <typename W>
+int amt_domain_poison_t(amt_domain *d, int sides, W nan)
+{
+    const long idim = d->ime - d->ims + 1, kdim = d->kme - d->kms + 1, jdim = d->jme - d->jms + 1;
+    AmtPoisonJobs<W> jobs{};
+    jobs.nan = nan;
+    auto row = [&](int f, int j) {
+        const long n = amt_field_rank(f) == 3 ? idim * kdim : idim;
+        const int q = jobs.n++;
+        jobs.base[q] = static_cast<W *>(d->field[f]) + (long)(j - d->jms) * n;
+        jobs.count[q] = n;
+        jobs.stride[q] = 1;
+    };
+    auto column = [&](int f, int i) {
+        const int q = jobs.n++;
+        jobs.base[q] = static_cast<W *>(d->field[f]) + (i - d->ims);
+        jobs.count[q] = amt_field_rank(f) == 3 ? kdim * jdim : jdim;
+        jobs.stride[q] = idim;
+    };
+    if ((sides & (AMT_SIDE_BELOW | AMT_SIDE_ABOVE)) && (d->jts - 1 < d->jms || d->jte + 1 > d->jme))
+        return amt_fail(AMT_ERR_PRECONDITION, "amt_domain_poison_halos: the patch holds no halo row below jts / above jte");
+    if ((sides & (AMT_SIDE_LEFT | AMT_SIDE_RIGHT)) && (d->its - 1 < d->ims || d->ite + 1 > d->ime))
+        return amt_fail(AMT_ERR_PRECONDITION, "amt_domain_poison_halos: the patch holds no halo column left of its / right of ite");
+    if (sides & AMT_SIDE_ABOVE) for (int f : {AMT_F_V, AMT_F_V_1, AMT_F_T_1, AMT_F_MUV, AMT_F_MSFVX_INV}) row(f, d->jte + 1);
+    if (sides & AMT_SIDE_BELOW) row(AMT_F_T_1, d->jts - 1);
+    if (sides & AMT_SIDE_RIGHT) for (int f : {AMT_F_U, AMT_F_U_1, AMT_F_T_1, AMT_F_MUU, AMT_F_MSFUY}) column(f, d->ite + 1);
+    if (sides & AMT_SIDE_LEFT) column(AMT_F_T_1, d->its - 1);
+    if (jobs.n == 0) return AMT_OK;
+    long most = 0;
+    for (int q = 0; q < jobs.n; ++q) most = jobs.count[q] > most ? jobs.count[q] : most;
+    long blocks = (most + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(amt_poison_kernel<W>, dim3((unsigned)blocks, (unsigned)jobs.n), dim3(256), 0, d->stream, jobs);
+    AMT_HIP(hipGetLastError());
+    return AMT_OK;
+}
+}  // namespace
+
+extern "C" int amt_domain_poison_halos(amt_domain *d, int sides)
+{
+    if (!d || (sides & ~15)) return amt_fail(AMT_ERR_INVALID_ARG, "bad poison argument");
+    DeviceScope scope(d->device);
+    return d->dtype_bytes == 8 ? amt_domain_poison_t<uint64_t>(d, sides, 0x7ff8000000000000ull)
+                               : amt_domain_poison_t<uint32_t>(d, sides, 0x7fc00000u);
+}
 
 template <typename T>
 static int amt_domain_step_t(amt_domain *d, int n_sweeps)

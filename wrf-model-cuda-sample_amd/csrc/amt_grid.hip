@@ -25,6 +25,7 @@ struct amt_grid {
     hipEvent_t halos_in = nullptr, col_done[2] = {nullptr, nullptr};
     hipEvent_t inputs_final = nullptr, edges_done = nullptr, t0 = nullptr, t1 = nullptr;
     int skew_us = 0;                                        // test hook: the neighbours' rows arrive this late
+    unsigned long long packs = 0;                           // exchanges begun (what AMT_TEST_FAULT skip_pack / skip_unpack count)
     // packed columns: what goes to the left / right neighbour, what came from the right / left one
     void *to_left = nullptr, *to_right = nullptr, *from_right = nullptr, *from_left = nullptr;
 };
@@ -109,8 +110,16 @@ int grid_columns(amt_grid *g, hipStream_t stream, bool scatter)
     AMT_HIP(hipGetLastError());
     return AMT_OK;
 }
-int grid_pack(amt_grid *g, hipStream_t s) { return g->dom->dtype_bytes == 8 ? grid_columns<uint64_t>(g, s, false) : grid_columns<uint32_t>(g, s, false); }
-int grid_unpack(amt_grid *g, hipStream_t s) { return g->dom->dtype_bytes == 8 ? grid_columns<uint64_t>(g, s, true) : grid_columns<uint32_t>(g, s, true); }
+int grid_pack(amt_grid *g, hipStream_t s)
+{
+    if (amt_test_fault("skip_pack", ++g->packs)) return AMT_OK;
+    return g->dom->dtype_bytes == 8 ? grid_columns<uint64_t>(g, s, false) : grid_columns<uint32_t>(g, s, false);
+}
+int grid_unpack(amt_grid *g, hipStream_t s)
+{
+    if (amt_test_fault("skip_unpack", g->packs)) return AMT_OK;
+    return g->dom->dtype_bytes == 8 ? grid_columns<uint64_t>(g, s, true) : grid_columns<uint32_t>(g, s, true);
+}
 
 // Test hook (amt_*_set_skew_us, RCCL transport): holds the communication stream for `ticks` of the 100 MHz real-time counter, so
 // that the exchange behind it starts -- and the neighbours' rows arrive -- that much late.  AMT_SLAB_SKEW_WGS=n (default 1) gives
@@ -217,7 +226,10 @@ int grid_step_t(amt_grid *g, int n_sweeps)
         }
     };
     for (int sweep = 0; sweep < n_sweeps; ++sweep) {
-        int rc = AMT_OK;
+        // a device-side wait of an EARLIER sweep that gave up (IPC transport: a neighbour that never posted or never pulled):
+        // that sweep's halo rows were not valid, so nothing is built on top of it -- the step fails here, not only in *_sync
+        int rc = amt_exchange_check(g->xchg);
+        if (rc) return rc;
         if (none) {                                                        // a world of one: the plain launch
             rc = grid_tile<T>(g, d->stream, ilo, ihi, jlo, jhi);
             if (rc) return rc;
@@ -395,7 +407,7 @@ int grid_step_timed(amt_grid *g, int n_sweeps, float *ms_total)
     float ms = 0.f;
     AMT_HIP(hipEventElapsedTime(&ms, g->t0, g->t1));
     if (ms_total) *ms_total = ms;
-    return AMT_OK;
+    return amt_exchange_check(g->xchg);          // the timed sweeps are complete: report a wait that gave up inside them
 }
 
 int grid_sync(amt_grid *g)

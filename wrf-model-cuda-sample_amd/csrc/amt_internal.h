@@ -28,6 +28,24 @@ int amt_fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 
     } while (0)
 
 // ---------------------------------------------------------------------------
+// Fault injection for the halo-freshness tests (tests/test_gpu_34_halo_freshness.py): AMT_TEST_FAULT="<step>@<n>" turns the
+// n-th occurrence (1-based, per exchange / per stepper) of one step of the halo exchange into a no-op, everything around it
+// -- sequence numbers, posts, waits -- running as usual, so that the sweep completes with STALE halo data instead of
+// hanging.  Steps: skip_stage (IPC: the staging copies of the send segments are not refreshed), skip_pull (IPC: the rows
+// are not pulled), skip_group (RCCL: the ncclSend/ncclRecv group is not issued -- every rank must carry the same setting),
+// skip_pack / skip_unpack (grid stepper: the halo columns are not gathered / scattered).  A test that cannot tell such a
+// run from a healthy one does not test the exchange beyond its first sweep.  Unset (always, outside those tests): no effect.
+// ---------------------------------------------------------------------------
+inline bool amt_test_fault(const char *step, unsigned long long occurrence)
+{
+    const char *spec = getenv("AMT_TEST_FAULT");          // read per call (a few times per sweep): a test sets and clears it in-process
+    if (!spec || !*spec) return false;
+    const char *at = strchr(spec, '@');
+    if (!at || (size_t)(at - spec) != strlen(step) || strncmp(spec, step, at - spec) != 0) return false;
+    return strtoull(at + 1, nullptr, 10) == occurrence;
+}
+
+// ---------------------------------------------------------------------------
 // argument bundle shared by the entry points
 // ---------------------------------------------------------------------------
 template <typename T>

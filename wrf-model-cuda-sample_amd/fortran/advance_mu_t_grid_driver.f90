@@ -12,11 +12,13 @@
 !   AMT_SLAB_TRANSPORT=ipc selects the RCCL-free transport (ranks may then share a device).
 !   AMT_GRID_POISON=1   overwrite every halo row / column that has a neighbour with NaN before stepping (only a working exchange
 !                       then gives finite results)
+!   AMT_GRID_REFRESH=1  one amt_grid_step per sweep, and before every sweep but the first NEW values in the fields that cross a
+!                       patch boundary (amt_domain_fill_fields, seed + sweep: the stand-in for advance_uv) and, with
+!                       AMT_GRID_POISON, NaN in the halos again: only an exchange that delivers every sweep gives the right bits
 !   AMT_GRID_DUMP_DIR   write the seven outputs of this rank (whole memory arrays, stream access) as <dir>/rank<r>_<name>.bin with
 !                       <dir>/rank<r>_bounds.txt for a checker (tests/test_gpu_33_grid_native.py holds the unsplit oracle run)
 program advance_mu_t_grid_driver
   use iso_c_binding
-  use, intrinsic :: ieee_arithmetic
   use amt_c_binding
   implicit none
 
@@ -30,14 +32,13 @@ program advance_mu_t_grid_driver
   character(kind=c_char), allocatable :: cpath(:)
   integer(c_int64_t), parameter :: seed = 12345_c_int64_t
   type(c_ptr) :: dom, grid, idptr
-  real(c_float) :: ms
+  real(c_float) :: ms, ms1
   real(wp), allocatable, target :: a3(:,:,:), a2(:,:)
-  real(wp) :: nan
+  integer :: sides
+  logical :: poison, refresh
   real(c_double) :: ms_job
   integer(c_int) :: crank, cworld
   integer(kind=8) :: c0, c1, crate
-  integer, parameter :: rows_from_above(5) = [AMT_F_V, AMT_F_V_1, AMT_F_T_1, AMT_F_MUV, AMT_F_MSFVX_INV]
-  integer, parameter :: cols_from_right(5) = [AMT_F_U, AMT_F_U_1, AMT_F_T_1, AMT_F_MUU, AMT_F_MSFUY]
   integer, parameter :: outputs(7) = [AMT_F_WW, AMT_F_T, AMT_F_T_AVE, AMT_F_MU, AMT_F_MUAVE, AMT_F_MUTS, AMT_F_MUDF]
   character(len=8), parameter :: output_names(7) = [character(len=8) :: 'ww', 't', 't_ave', 'mu', 'muave', 'muts', 'mudf']
 
@@ -77,17 +78,15 @@ program advance_mu_t_grid_driver
                  'amt_domain_fill_synthetic')
   allocate (a3(ims:ime, kms:kme, jms:jme), a2(ims:ime, jms:jme))
 
-  if (env_int('AMT_GRID_POISON', 0) /= 0) then
-     nan = ieee_value(nan, ieee_quiet_nan)
-     do n = 1, 5
-        f = rows_from_above(n)
-        if (rj < pj - 1) call poison(f, 0, jme)
-        f = cols_from_right(n)
-        if (ri < pi - 1) call poison(f, ite + 1, 0)
-     end do
-     if (rj > 0) call poison(AMT_F_T_1, 0, jms)
-     if (ri > 0) call poison(AMT_F_T_1, its - 1, 0)
-  end if
+  ! the sides on which this patch reads a neighbour's rows / columns
+  sides = 0
+  if (rj > 0) sides = sides + AMT_SIDE_BELOW
+  if (rj < pj - 1) sides = sides + AMT_SIDE_ABOVE
+  if (ri > 0) sides = sides + AMT_SIDE_LEFT
+  if (ri < pi - 1) sides = sides + AMT_SIDE_RIGHT
+  poison = env_int('AMT_GRID_POISON', 0) /= 0
+  refresh = env_int('AMT_GRID_REFRESH', 0) /= 0
+  if (poison) call amt_check(amt_domain_poison_halos(dom, int(sides, c_int)), 'amt_domain_poison_halos')
 
   idptr = c_null_ptr
   if (world > 1) then
@@ -111,7 +110,24 @@ program advance_mu_t_grid_driver
 
   call amt_check(amt_grid_barrier(grid), 'amt_grid_barrier')
   call system_clock(c0, crate)
-  call amt_check(amt_grid_step_timed(grid, int(nsweeps, c_int), ms), 'amt_grid_step_timed')
+  if (refresh) then
+     ! what a host model does: before every sub-step but the first the fields that cross a patch boundary get new values
+     ! (amt_domain_fill_fields with seed + sweep stands in for advance_uv rewriting u, v), and -- for verification -- the halos
+     ! are poisoned again: only an exchange that delivers THIS sweep's rows and columns gives the unsplit run's bits
+     ms = 0.0
+     do n = 0, nsweeps - 1
+        if (n > 0) then
+           call amt_check(amt_domain_fill_fields(dom, AMT_EXCHANGED_FIELDS, seed + int(n, c_int64_t), int(ims, c_long),    &
+                                                 int(kms - 1, c_long), int(jms, c_long), int(ni + 2, c_long),            &
+                                                 int(nk + 1, c_long), int(nj + 2, c_long)), 'amt_domain_fill_fields')
+           if (poison) call amt_check(amt_domain_poison_halos(dom, int(sides, c_int)), 'amt_domain_poison_halos')
+        end if
+        call amt_check(amt_grid_step_timed(grid, 1_c_int, ms1), 'amt_grid_step_timed')
+        ms = ms + ms1
+     end do
+  else
+     call amt_check(amt_grid_step_timed(grid, int(nsweeps, c_int), ms), 'amt_grid_step_timed')
+  end if
   call amt_check(amt_grid_sync(grid), 'amt_grid_sync')
   call system_clock(c1)
   ms_job = real(c1 - c0, 8) * 1.0d3 / real(crate, 8)
@@ -149,22 +165,6 @@ program advance_mu_t_grid_driver
   call amt_check(amt_domain_destroy(dom), 'amt_domain_destroy')
 
 contains
-
-  ! NaN into memory column `col` (col /= 0 ... a Fortran i index) or memory row `row` (row /= 0) of field f
-  subroutine poison(field, col, row)
-    integer, intent(in) :: field, col, row
-    if (field == AMT_F_MUV .or. field == AMT_F_MSFVX_INV .or. field == AMT_F_MUU .or. field == AMT_F_MSFUY) then
-       call amt_check(amt_domain_download(dom, int(field, c_int), c_loc(a2)), 'amt_domain_download')
-       if (row /= 0) a2(:, row) = nan
-       if (col /= 0) a2(col, :) = nan
-       call amt_check(amt_domain_upload(dom, int(field, c_int), c_loc(a2)), 'amt_domain_upload')
-    else
-       call amt_check(amt_domain_download(dom, int(field, c_int), c_loc(a3)), 'amt_domain_download')
-       if (row /= 0) a3(:, :, row) = nan
-       if (col /= 0) a3(col, :, :) = nan
-       call amt_check(amt_domain_upload(dom, int(field, c_int), c_loc(a3)), 'amt_domain_upload')
-    end if
-  end subroutine poison
 
   function itoa(v) result(s)
     integer, intent(in) :: v

@@ -13,6 +13,8 @@
 !         --master-addr 127.0.0.1 --master-port 29533 ./advance_mu_t_slab_driver_f64 4096 60 4096 20
 !   (or mpirun with the same variables exported).  Without them: one rank, no communicator.
 !   AMT_RENDEZVOUS_FILE overrides the file through which rank 0 hands out the communicator id.
+!   AMT_SLAB_REFRESH=1: one amt_slab_step per sweep with new values in the exchanged fields and re-poisoned halo rows before each
+!   (see next_inputs below); the timed figure then includes nothing but the sweeps (the refills are outside the events).
 !
 !   advance_mu_t_slab_driver [NI NK NJ [nsweeps [loopback]]]
 !     loopback = 1: one-rank self test, the rank is its own neighbour (exercises RCCL and the
@@ -32,7 +34,9 @@ program advance_mu_t_slab_driver
   character(kind=c_char), allocatable :: cpath(:)
   integer(c_int64_t), parameter :: seed = 12345_c_int64_t
   type(c_ptr) :: dom, slab, idptr
-  real(c_float) :: ms
+  real(c_float) :: ms, ms1
+  integer :: sides
+  logical :: refresh
   real(wp), allocatable, target :: mu(:,:)
   real(kind=8) :: cells, bytes
   real(c_double) :: ms_job
@@ -100,10 +104,27 @@ program advance_mu_t_slab_driver
   end if
   call amt_check(amt_slab_create(slab, dom, int(rank, c_int), int(world, c_int), idptr, int(flags, c_int)), 'amt_slab_create')
 
-  call amt_check(amt_slab_step(slab, 2_c_int), 'amt_slab_step (warm-up)')   ! code objects, RCCL connections
+  refresh = env_int('AMT_SLAB_REFRESH', 0) /= 0
+  sides = 0
+  if (rank > 0 .or. loopback /= 0) sides = sides + AMT_SIDE_BELOW
+  if (rank < world - 1 .or. loopback /= 0) sides = sides + AMT_SIDE_ABOVE
+  if (refresh) call amt_check(amt_domain_poison_halos(dom, int(sides, c_int)), 'amt_domain_poison_halos')
+  call next_inputs(1)
+  call amt_check(amt_slab_step(slab, 1_c_int), 'amt_slab_step (warm-up)')   ! code objects, RCCL connections
+  call next_inputs(2)
+  call amt_check(amt_slab_step(slab, 1_c_int), 'amt_slab_step (warm-up)')
   call amt_check(amt_slab_barrier(slab), 'amt_slab_barrier')                ! every rank starts the clock together
   call system_clock(c0, crate)
-  call amt_check(amt_slab_step_timed(slab, int(nsweeps, c_int), ms), 'amt_slab_step_timed')
+  if (refresh) then
+     ms = 0.0
+     do n = 1, nsweeps
+        call next_inputs(2 + n)
+        call amt_check(amt_slab_step_timed(slab, 1_c_int, ms1), 'amt_slab_step_timed')
+        ms = ms + ms1
+     end do
+  else
+     call amt_check(amt_slab_step_timed(slab, int(nsweeps, c_int), ms), 'amt_slab_step_timed')
+  end if
   call amt_check(amt_slab_sync(slab), 'amt_slab_sync')
   call system_clock(c1)
   ! the sweep time of the JOB is the slowest rank's (a rank's own event time excludes the wait
@@ -131,6 +152,18 @@ program advance_mu_t_slab_driver
   call amt_check(amt_domain_destroy(dom), 'amt_domain_destroy')
 
 contains
+
+  ! AMT_SLAB_REFRESH=1: before sweep number `sweep` (1-based; not before the first) the fields that cross a slab boundary get new
+  ! values -- amt_domain_fill_fields with seed + sweep - 1 stands in for advance_uv rewriting u, v before every advance_mu_t call --
+  ! and the halo rows are poisoned with NaN again: only an exchange that delivers every sweep then gives the unsplit run's result
+  subroutine next_inputs(sweep)
+    integer, intent(in) :: sweep
+    if (.not. refresh .or. sweep <= 1) return
+    call amt_check(amt_domain_fill_fields(dom, AMT_EXCHANGED_FIELDS, seed + int(sweep - 1, c_int64_t), int(ims, c_long),     &
+                                          int(kms - 1, c_long), int(jms, c_long), int(ni + 2, c_long), int(nk + 1, c_long), &
+                                          int(nj + 2, c_long)), 'amt_domain_fill_fields')
+    call amt_check(amt_domain_poison_halos(dom, int(sides, c_int)), 'amt_domain_poison_halos')
+  end subroutine next_inputs
 
   integer function env_int(name, dflt) result(v)
     character(len=*), intent(in) :: name

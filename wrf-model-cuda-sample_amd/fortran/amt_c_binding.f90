@@ -181,6 +181,25 @@ MODULE amt_c_binding
          integer(c_int) :: rc
       end function
 
+      ! the fields of field_mask only (bit f = field id f; AMT_EXCHANGED_FIELDS below): the stand-in for advance_uv
+      ! rewriting u, v before every advance_mu_t call
+      function amt_domain_fill_fields(handle, field_mask, seed, gi0, gk0, gj0, gidim, gkdim, gjdim) &
+            bind(C, name="amt_domain_fill_fields") result(rc)
+         import :: c_ptr, c_int, c_int64_t, c_long
+         type(c_ptr), value :: handle
+         integer(c_int64_t), value :: field_mask, seed
+         integer(c_long), value :: gi0, gk0, gj0, gidim, gkdim, gjdim
+         integer(c_int) :: rc
+      end function
+
+      ! NaN into what the stencil reads from a neighbour: sides = sum of AMT_SIDE_BELOW / ABOVE / LEFT / RIGHT
+      function amt_domain_poison_halos(handle, sides) bind(C, name="amt_domain_poison_halos") result(rc)
+         import :: c_ptr, c_int
+         type(c_ptr), value :: handle
+         integer(c_int), value :: sides
+         integer(c_int) :: rc
+      end function
+
       ! ---- j-slabs over several GPUs, one process per GPU (RCCL halos) ----
       function amt_set_device(device) bind(C, name="amt_set_device") result(rc)
          import :: c_int
@@ -327,6 +346,12 @@ MODULE amt_c_binding
       AMT_F_MUV = 11, AMT_F_MUDF = 12, AMT_F_T = 13, AMT_F_T_1 = 14, AMT_F_T_AVE = 15, AMT_F_FT = 16,       &
       AMT_F_MU_TEND = 17, AMT_F_DNW = 18, AMT_F_FNM = 19, AMT_F_FNP = 20, AMT_F_RDNW = 21,                  &
       AMT_F_MSFUY = 22, AMT_F_MSFVX_INV = 23, AMT_F_MSFTX = 24, AMT_F_MSFTY = 25
+   ! AMT_EXCHANGED_FIELDS: u, u_1, v, v_1, t_1, muu, muv, msfuy, msfvx_inv -- what crosses a patch boundary
+   integer(c_int64_t), parameter :: AMT_EXCHANGED_FIELDS = ior(ior(ior(ishft(1_c_int64_t, 2), ishft(1_c_int64_t, 3)),       &
+      ior(ishft(1_c_int64_t, 4), ishft(1_c_int64_t, 5))), ior(ior(ishft(1_c_int64_t, 14), ishft(1_c_int64_t, 10)),          &
+      ior(ishft(1_c_int64_t, 11), ior(ishft(1_c_int64_t, 22), ishft(1_c_int64_t, 23)))))
+   ! enum amt_sides (amt_domain_poison_halos)
+   integer(c_int), parameter :: AMT_SIDE_BELOW = 1, AMT_SIDE_ABOVE = 2, AMT_SIDE_LEFT = 4, AMT_SIDE_RIGHT = 8
 
 CONTAINS
 

@@ -62,6 +62,8 @@ SYMBOLS = {
     "amt_domain_upload_rows": (_I, [_P, _I, _I, _I, _P]),
     "amt_domain_download_rows": (_I, [_P, _I, _I, _I, _P]),
     "amt_domain_fill_synthetic": (_I, [_P, ctypes.c_uint64] + [_L] * 6),
+    "amt_domain_fill_fields": (_I, [_P, ctypes.c_uint64, ctypes.c_uint64] + [_L] * 6),
+    "amt_domain_poison_halos": (_I, [_P, _I]),
     "amt_domain_step": (_I, [_P, _I]),
     "amt_domain_tune_placement": (_I, [_P, _I, ctypes.POINTER(ctypes.c_float)]),
     "amt_domain_placement": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),

@@ -21,12 +21,21 @@ from __future__ import annotations
 
 from typing import Callable, Optional
 
+from . import synth as _S
 from .synth import Patch, HALO_FROM_ABOVE, HALO_FROM_BELOW
 
 
 def _dist():
     import torch.distributed as dist
     return dist
+
+
+def _fault(step: str, occurrence: int) -> bool:
+    """AMT_TEST_FAULT="<step>@<n>" (csrc/amt_internal.h): the n-th exchange of a torch stepper is skipped by every rank
+    ("skip_exchange") -- the halo-freshness tests must turn red on it.  Unset outside those tests."""
+    import os
+    spec = os.environ.get("AMT_TEST_FAULT", "")
+    return bool(spec) and spec == f"{step}@{occurrence}"
 
 
 class SlabStepper:
@@ -90,6 +99,9 @@ class SlabStepper:
     def exchange_halos(self):
         """Post the sends/receives of one sweep and wait for them on the current stream
         (device-side wait for RCCL; host wait for gloo)."""
+        self._exchanges = getattr(self, "_exchanges", 0) + 1
+        if _fault("skip_exchange", self._exchanges):
+            return
         if self.transport is not None:
             self.transport(self)
             return
@@ -177,8 +189,7 @@ class SlabStepper:
 
 # i-direction halos (module_small_step_em.f90:145 reads u, u_1, muu, msfuy at i+1; :244-245 read
 # t_1 at i+1 and i-1)
-HALO_FROM_RIGHT = ("u", "u_1", "t_1", "muu", "msfuy")
-HALO_FROM_LEFT = ("t_1",)
+from .synth import HALO_FROM_RIGHT, HALO_FROM_LEFT  # noqa: E402  (re-exported: tests name them through this module)
 
 
 class GridStepper:
@@ -220,6 +231,9 @@ class GridStepper:
     def exchange_halos(self):
         if self._native is not None:
             return self._native.exchange_halos()
+        self._exchanges = getattr(self, "_exchanges", 0) + 1
+        if _fault("skip_exchange", self._exchanges):
+            return
         dist = _dist()
         a = self.patch.arrays
         jdim = self.patch.bounds.jdim
@@ -278,6 +292,20 @@ class GridStepper:
             self.compute(*args)
 
 
+def _substep_inputs(stepper, dom, seed, sweep, sides):
+    """amt_domain_fill_fields(AMT_EXCHANGED_FIELDS, seed + sweep) [+ amt_domain_poison_halos(sides)] on the domain's stream."""
+    b = stepper.patch.bounds
+    gdims = stepper.patch.global_dims or (b.ide - b.ids, b.kde - 1, b.jde - b.jds)
+    mask = 0
+    for name in _S.EXCHANGED_INPUTS:
+        mask |= 1 << _S.FIELD_ID[name]
+    with stepper._dev():
+        stepper._lib.check(stepper.L.amt_domain_fill_fields(dom, mask, _S.sweep_seed(seed, sweep), b.ims, b.kms - 1, b.jms,
+                                                            gdims[0] + 2, gdims[1] + 1, gdims[2] + 2))
+        if sides:
+            stepper._lib.check(stepper.L.amt_domain_poison_halos(dom, sides))
+
+
 class NativeSlabStepper:
     """The same j-slab sweep as ``SlabStepper`` driven by the C++ runtime behind the C-ABI
     (``amt_slab_*``, include/amt_advance_mu_t.h section 5): ``ncclSend/ncclRecv`` of the halo rows
@@ -306,6 +334,7 @@ class NativeSlabStepper:
         self.patch, self.rank, self.world = patch, rank, world
         self.below: Optional[int] = rank - 1 if rank > 0 else None
         self.above: Optional[int] = rank + 1 if rank < world - 1 else None
+        self._halo_sides = (_S.SIDE_BELOW | _S.SIDE_ABOVE) if loopback else _S.neighbour_sides(0, rank, 1, world)
         t0 = patch.arrays["t_1"]
         if not t0.is_cuda:
             raise TypeError("NativeSlabStepper needs a device patch (there is no CPU path)")
@@ -362,6 +391,13 @@ class NativeSlabStepper:
         with self._dev():
             self._lib.check(self.L.amt_slab_sync(self._slab))
 
+    def next_substep_inputs(self, seed: int, sweep: int, poison: bool = True):
+        """What a host model does between two calls: new values in the fields that cross a slab boundary (the stand-in for
+        advance_uv: amt_domain_fill_fields with AMT_EXCHANGED_FIELDS, seed + sweep) and, for verification, NaN in the halo
+        rows (amt_domain_poison_halos) -- both on the domain's stream.  Only an exchange that delivers THIS sweep's rows
+        then gives the bits of the unsplit run."""
+        _substep_inputs(self, self._dom, seed, sweep, self._halo_sides if poison else 0)
+
     def set_skew_us(self, microseconds: int):
         """Test hook: every later sweep's exchange starts this late on the communication stream (neighbour skew)."""
         self._lib.check(self.L.amt_slab_set_skew_us(self._slab, int(microseconds)))
@@ -417,6 +453,7 @@ class NativeGridStepper:
         self._lib, self._ct = _lib, ctypes
         self.L = L = _lib.load_library()
         self.patch, self.ri, self.rj, self.pi, self.pj = patch, ri, rj, pi, pj
+        self._halo_sides = 15 if loopback else _S.neighbour_sides(ri, rj, pi, pj)
         t0 = patch.arrays["t_1"]
         if not t0.is_cuda:
             raise TypeError("NativeGridStepper needs a device patch (there is no CPU path)")
@@ -465,6 +502,10 @@ class NativeGridStepper:
     def sync(self):
         with self._dev():
             self._lib.check(self.L.amt_grid_sync(self._grid))
+
+    def next_substep_inputs(self, seed: int, sweep: int, poison: bool = True):
+        """As NativeSlabStepper.next_substep_inputs, for the halo rows AND columns of a patch."""
+        _substep_inputs(self, self._dom, seed, sweep, self._halo_sides if poison else 0)
 
     def halo_bytes_per_sweep(self) -> int:
         return int(self.L.amt_grid_halo_bytes(self._grid))           # sent + received

@@ -270,3 +270,74 @@ def make_patch(b: Bounds, config: GridConfig = GridConfig(), dtype=np.float64, s
                 arrays[name] = a
         return Patch(b, config, arrays, RDX, RDY, DTS, EPSSM, tuple(global_dims), owner)
     return Patch(b, config, arrays, RDX, RDY, DTS, EPSSM, tuple(global_dims))
+
+
+# ---------------------------------------------------------------------------------------------
+# Inputs that change every sub-step.  In WRF advance_uv rewrites u and v before every advance_mu_t
+# call, and the fields a patch sends to its neighbours (module_small_step_em.f90:143-146, 241-245)
+# are what that call reads across the boundary: freshness is the point of a per-sub-step exchange.
+# A static benchmark keeps them constant, and then an exchange that delivers ONCE satisfies every
+# later sweep.  These helpers give sweep s (0-based) its own inputs -- the exchanged fields refilled
+# from the generator with seed + s -- on the host (the checker's unsplit run) and on a device patch.
+# ---------------------------------------------------------------------------------------------
+EXCHANGED_INPUTS = ("u", "u_1", "v", "v_1", "t_1", "muu", "muv", "msfuy", "msfvx_inv")   # AMT_EXCHANGED_FIELDS
+HALO_FROM_RIGHT = ("u", "u_1", "t_1", "muu", "msfuy")                                   # column i+1 is read (:145, :244)
+HALO_FROM_LEFT = ("t_1",)                                                               # column i-1 is read (:245)
+SIDE_BELOW, SIDE_ABOVE, SIDE_LEFT, SIDE_RIGHT = 1, 2, 4, 8                              # enum amt_sides
+
+
+def sweep_seed(seed: int, sweep: int) -> int:
+    """Seed of the exchanged inputs of sweep ``sweep`` (0-based; sweep 0 = the patch as made)."""
+    return int(seed) + int(sweep)
+
+
+def refresh_exchanged_inputs(patch: Patch, seed: int, sweep: int, stream=None) -> None:
+    """Refill EXCHANGED_INPUTS of ``patch`` (whole local arrays, halos included) for sweep ``sweep``.
+    Host patches: amt_synth_fill_host; device patches: amt_synth_fill_device on ``stream`` (default: torch's current)."""
+    L = _lib.load_library()
+    b = patch.bounds
+    gdims = patch.global_dims or (b.ide - b.ids, b.kde - 1, b.jde - b.jds)
+    s = ctypes.c_uint64(sweep_seed(seed, sweep))
+    for name in EXCHANGED_INPUTS:
+        a = patch.arrays[name]
+        fa, _ = _fill_args(b, name, gdims)
+        if hasattr(a, "is_cuda"):
+            if a.is_cuda:
+                import torch
+                st = stream if stream is not None else torch.cuda.current_stream(a.device)
+                with torch.cuda.device(a.device):
+                    _lib.check(L.amt_synth_fill_device(ctypes.c_void_p(st.cuda_stream), FIELD_ID[name], a.element_size(),
+                                                       ctypes.c_void_p(a.data_ptr()), s, *fa))
+            else:                                         # a CPU tensor (the gloo tests): fill the memory it views
+                _lib.check(L.amt_synth_fill_host(FIELD_ID[name], a.element_size(), ctypes.c_void_p(a.data_ptr()), s, *fa))
+        else:
+            _lib.check(L.amt_synth_fill_host(FIELD_ID[name], a.dtype.itemsize, a.ctypes.data_as(ctypes.c_void_p), s, *fa))
+
+
+def poison_halos(patch: Patch, sides: int) -> None:
+    """NaN into exactly what the stencil reads from a neighbour on ``sides`` (SIDE_* or-ed): row jte+1 of HALO_FROM_ABOVE,
+    row jts-1 of t_1, column ite+1 of HALO_FROM_RIGHT, column its-1 of t_1.  Works on numpy arrays and torch tensors
+    (device tensors: on torch's current stream)."""
+    b, a, nan = patch.bounds, patch.arrays, float("nan")
+
+    def fill(view):
+        view.fill_(nan) if hasattr(view, "fill_") else view.fill(nan)
+
+    if sides & SIDE_ABOVE:
+        for n in HALO_FROM_ABOVE:
+            fill(a[n][b.jte + 1 - b.jms])
+    if sides & SIDE_BELOW:
+        for n in HALO_FROM_BELOW:
+            fill(a[n][b.jts - 1 - b.jms])
+    if sides & SIDE_RIGHT:
+        for n in HALO_FROM_RIGHT:
+            fill(a[n][..., b.ite + 1 - b.ims])
+    if sides & SIDE_LEFT:
+        for n in HALO_FROM_LEFT:
+            fill(a[n][..., b.its - 1 - b.ims])
+
+
+def neighbour_sides(ri: int, rj: int, pi: int, pj: int) -> int:
+    """The sides of patch (ri, rj) of pi x pj that have a neighbour."""
+    return ((SIDE_BELOW if rj > 0 else 0) | (SIDE_ABOVE if rj < pj - 1 else 0)
+            | (SIDE_LEFT if ri > 0 else 0) | (SIDE_RIGHT if ri < pi - 1 else 0))
