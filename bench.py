@@ -91,10 +91,20 @@ def parse():
                          "the ranks really run (two processes, one device: a correctness run of the whole N > 1 path, never a "
                          "scaling number); with the RCCL transport this drives the failure path (RCCL refuses two ranks on one "
                          "device: diagnosis, clean non-zero exit of every rank)")
-    ap.add_argument("--transport", choices=("rccl", "ipc"), default="rccl",
+    ap.add_argument("--transport", choices=("both", "rccl", "ipc"), default="both",
                     help="N > 1, native stepper: what carries the halo rows -- rccl = ncclSend/ncclRecv (north_star's transport); "
                          "ipc = hipIpcMemHandles + a shared-memory mailbox + copy-engine pulls between the processes of one "
-                         "node (no RCCL; no compute unit held while the wire is busy; ranks may share a device)")
+                         "node (no RCCL; no compute unit held while the wire is busy; ranks may share a device); both (default) = "
+                         "time one after the other, each in fresh rank processes: `value` is RCCL's (north_star's transport) when it "
+                         "ran, the IPC figures stand beside it under `transports`")
+    ap.add_argument("--rung-timeout", type=float, default=180.0,
+                    help="N > 1: most seconds one rung of the ladder (one transport's child process of a rank: set-up, verification, "
+                         "warm-up, timed sweeps) may take before the rank's supervisor ends it and goes on to the next rung")
+    ap.add_argument("--rung-child", default="", help=argparse.SUPPRESS)     # internal: this process is one rank's child of a rung
+    ap.add_argument("--wrf-rows-steps", type=int, default=5,
+                    help="N = 1: after the headline (padded rows) re-create the state with WRF's own unpadded memory extents "
+                         "(ims:ime = 0:NI+1) and time this many sweeps -> `wrf_rows` in the line; 0 = skip")
+    ap.add_argument("--traffic-layouts", default="", help=argparse.SUPPRESS)  # internal: PMC child runs these --align-elems values in turn
     ap.add_argument("--beside-rounds", type=int, default=0,
                     help="N > 1: least rounds of workgroups of a slab's interior launch (amt_march_set_beside; 0 = library default 2)")
     ap.add_argument("--beside-reserve", type=int, default=0,
@@ -186,12 +196,14 @@ def box_ceilings(pkg, stream, device, nbytes=4 << 30):
     return out, under_load
 
 
-def measure_traffic(a, seconds=150.0):
-    """HBM bytes of one launch ON THIS BOX, in this run: two child runs of this same script (two sweeps each) under
-    `rocprofv3 --kernel-trace --kernel-include-regex amt_ --pmc FETCH_SIZE` / `... WRITE_SIZE` -- separate passes, the
-    program directly after `--`, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- and the gfx950 correction of
-    profiles/README.md (FETCH_SIZE counts half of a streamed read).  Returns (read_bytes, write_bytes, note) or raises;
-    the caller has released its own arrays first.  Each pass is its own process group under a timeout."""
+def measure_traffic(a, layouts, seconds=150.0):
+    """HBM bytes of one launch ON THIS BOX, in this run, for every memory layout in `layouts` (--align-elems values; 1 = WRF's own
+    unpadded rows): two child runs of this same script under `rocprofv3 --kernel-trace --kernel-include-regex amt_ --pmc
+    FETCH_SIZE` / `... WRITE_SIZE` -- separate passes, the program directly after `--`, as /opt/skills/guides/MI355X_MICROARCH.md
+    prescribes -- each child building one layout after the other and running three sweeps on it; the launches are told apart by
+    their dispatch order.  gfx950 correction of profiles/README.md: FETCH_SIZE counts half of a streamed read.  Returns
+    ({align: (read_bytes, write_bytes)}, note) or raises; the caller has released its own arrays first.  Each pass is its own
+    process group under a timeout."""
     import csv
     import glob
     import shutil
@@ -202,15 +214,15 @@ def measure_traffic(a, seconds=150.0):
         raise RuntimeError("rocprofv3 not on PATH")
     if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         raise RuntimeError("this process is itself running under a profiler: no nested rocprofv3 passes")
+    per_layout = 3                                            # 1 warm-up + 2 sweeps per layout in the child
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="amt_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--output-format", "csv", "--kernel-trace", "--kernel-include-regex", "amt_march|amt_column",
                "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, str(Path(__file__).resolve()),
                "--ni", str(a.ni), "--nk", str(a.nk), "--nj", str(a.nj), "--dtype", a.dtype, "--variant", str(a.variant),
-               "--seed", str(a.seed), "--align-elems", str(a.align_elems), "--idim-extra", str(a.idim_extra),
-               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-verify", "--no-box-probe",
-               "--probe-placements", "1", "--no-traffic"]
+               "--seed", str(a.seed), "--idim-extra", str(a.idim_extra), "--traffic-layouts", ",".join(str(x) for x in layouts),
+               "--steps", "2", "--warmup", "1"]
         p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp",
                              env=dict(os.environ, TMPDIR="/tmp"), start_new_session=True)
         try:
@@ -226,20 +238,46 @@ def measure_traffic(a, seconds=150.0):
         vals = []
         for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
             with open(f, newline="") as fh:
-                for r in csv.DictReader(fh):
+                for n, r in enumerate(csv.DictReader(fh)):
                     if r.get("Counter_Name") == counter and "amt_" in r.get("Kernel_Name", ""):
-                        vals.append(float(r["Counter_Value"]))
+                        try:
+                            order = int(r.get("Dispatch_Id") or n)
+                        except ValueError:
+                            order = n
+                        vals.append((order, float(r["Counter_Value"])))
         shutil.rmtree(out, ignore_errors=True)
-        if p.returncode != 0 or not vals:
-            raise RuntimeError(f"the {counter} pass gave no data (exit {p.returncode})")
-        got[counter] = (sum(vals) / len(vals), len(vals))
-    rd = 2.0 * got["FETCH_SIZE"][0] * 1024.0
-    wr = got["WRITE_SIZE"][0] * 1024.0
+        vals = [v for _, v in sorted(vals)]
+        if p.returncode != 0 or len(vals) != per_layout * len(layouts):
+            raise RuntimeError(f"the {counter} pass gave {len(vals)} launches, expected {per_layout * len(layouts)} (exit {p.returncode})")
+        for k, al in enumerate(layouts):
+            mine = vals[k * per_layout: (k + 1) * per_layout]
+            got.setdefault(al, {})[counter] = sum(mine) / len(mine)
+    res = {al: (2.0 * c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0) for al, c in got.items()}
     note = (f"measured in this run on this box: child runs of this command under rocprofv3 --kernel-trace --pmc FETCH_SIZE and "
-            f"--pmc WRITE_SIZE (separate passes, {got['FETCH_SIZE'][1]} + {got['WRITE_SIZE'][1]} launches; KiB per launch "
-            f"{got['FETCH_SIZE'][0]:.0f} / {got['WRITE_SIZE'][0]:.0f}); HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 "
-            f"calibration of profiles/README.md")
-    return rd, wr, note
+            f"--pmc WRITE_SIZE (separate passes, {per_layout} launches per layout, layouts --align-elems {list(layouts)} one after the other "
+            f"in each child); HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 calibration of profiles/README.md")
+    return res, note
+
+
+def traffic_child(a):
+    """The program rocprofv3 runs for measure_traffic: for every layout of --traffic-layouts the state, 1 + 2 sweeps, nothing else."""
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    S = pkg.synth
+    torch.cuda.set_device(0)
+    dtype = np.float64 if a.dtype == "f64" else np.float32
+    os.environ["AMT_DOMAIN_PLACEMENT_TRIES"] = "1"
+    for al in [int(x) for x in a.traffic_layouts.split(",")]:
+        gb = S.domain_bounds(a.ni, a.nk, a.nj, aligned=True, align_elems=al)
+        gb = gb.replace(ime=gb.ime + a.idim_extra)
+        dev = S.make_patch(gb, pkg.GridConfig(), dtype=dtype, seed=a.seed, global_dims=(a.ni, a.nk, a.nj), device="cuda:0", native_domain=True)
+        call = pkg.advance_mu_t.bind(*dev.args(), variant=a.variant)
+        for _ in range(a.warmup + a.steps):
+            call()
+        torch.cuda.synchronize()
+        del call, dev
+        torch.cuda.empty_cache()
 
 
 def ramp_clocks(pkg, stream, tensor, max_seconds=3.0):
@@ -289,26 +327,6 @@ def algorithmic_bytes(ni, nk, nj, itemsize):
     return itemsize * ni * nj * (11 * nk + 14)
 
 
-def verify_first_sweep(pkg, oracle, dev, gb, dims, dtype, seed, rank_rows):
-    """After exactly one sweep from fresh inputs: recompute a few 3-row j-slabs with the oracle
-    from regenerated inputs and compare bit for bit (size-independent parity check)."""
-    S = pkg.synth
-    b = dev.bounds
-    jlo_own, jhi_own = rank_rows
-    cand = sorted({jlo_own, max(jlo_own, jhi_own - 2), (jlo_own + jhi_own) // 2})
-    for jlo in cand:
-        jhi = min(jlo + 2, jhi_own)
-        sb = gb.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
-        want = S.make_patch(sb, dev.config, dtype=dtype, seed=seed, global_dims=dims)
-        oracle.advance_mu_t_omp(*want.args(), nthreads=min(3, jhi - jlo + 1))
-        for n in S.OUTPUTS:
-            got = dev.arrays[n][jlo - b.jms: jhi + 1 - b.jms].cpu().numpy()
-            w = want.arrays[n][1: 1 + (jhi - jlo + 1)]
-            if not np.array_equal(got.view(np.uint8), w.view(np.uint8)):
-                return False, f"rows {jlo}..{jhi} of {n} differ from the oracle"
-    return True, ""
-
-
 def fp32_error_vs_fp64(pkg, oracle, dev, gb, dims, seed, rank_rows):
     """BASELINE.json configs[4]: the fp32 run judged against the fp64 Fortran (oracle in fp64 on a
     3-row slab of regenerated fp64 inputs).  Returns max over the outputs of max|fp32-fp64| / max|fp64|."""
@@ -355,7 +373,7 @@ def mem_available_bytes():
     return None
 
 
-def cpu_baseline(dims, dtype_name, seed, rows, seconds):
+def cpu_baseline(dims, dtype_name, seed, rows, seconds, prebuild=None):
     """SURVEY.md section 8(d) / BASELINE.md section 4, timed on this box's host cores in the same run:
 
       fortran           the build's own Fortran-90 CPU path (oracle/fortran/advance_mu_t_cpu.f90: same
@@ -388,17 +406,23 @@ def cpu_baseline(dims, dtype_name, seed, rows, seconds):
     # amdclang / gcc, which belongs neither to the leg's budget nor to any entry's timeout (r03: the first entry's 32 s
     # timeout ended inside the compile on the driver's box and the line went out with value null).
     t_build = time.perf_counter()
-    prebuild = None
+    overlapped = prebuild is not None
     try:
-        r = subprocess.run([sys.executable, worker, "--prebuild"], capture_output=True, text=True, timeout=600)
-        prebuild = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
-        if r.returncode != 0:
-            errors.append(f"prebuild: exit {r.returncode}: {r.stderr.strip()[-300:]}")
-        elif prebuild and prebuild.get("failed"):
-            errors.extend(f"prebuild: {x}" for x in prebuild["failed"])
+        if prebuild is not None:                      # started at the top of the run, beside the GPU part: join it
+            so, se = prebuild["proc"].communicate(timeout=600)
+            rcode = prebuild["proc"].returncode
+        else:
+            r = subprocess.run([sys.executable, worker, "--prebuild"], capture_output=True, text=True, timeout=600)
+            so, se, rcode = r.stdout, r.stderr, r.returncode
+        built = json.loads(so.strip().splitlines()[-1]) if rcode == 0 and so.strip() else None
+        if rcode != 0:
+            errors.append(f"prebuild: exit {rcode}: {se.strip()[-300:]}")
+        elif built and built.get("failed"):
+            errors.extend(f"prebuild: {x}" for x in built["failed"])
     except Exception as e:  # noqa: BLE001
         errors.append(f"prebuild: {type(e).__name__}: {str(e)[-300:]}")
-    build_seconds = round(time.perf_counter() - t_build, 1)
+    build_seconds = round(time.perf_counter() - t_build, 1)          # overlapped: only what was left to wait for
+    build_total = round(time.perf_counter() - prebuild["t0"], 1) if overlapped else build_seconds
     t_leg = time.perf_counter()
 
 
@@ -502,6 +526,7 @@ def cpu_baseline(dims, dtype_name, seed, rows, seconds):
            "host": quota_note + (f", MemAvailable {avail / 2**30:.0f} GiB" if avail else ""),
            "leg_seconds": round(time.perf_counter() - t_leg, 1),
            "build_seconds_not_in_the_budget": build_seconds,
+           "build_overlapped_with_the_gpu_part": overlapped, "build_seconds_since_the_start_of_the_run": build_total,
            "matrix": matrix}
     ref = [m for m in matrix if m["impl"] == "reference_fortran_compute_only"]
     if ref:
@@ -661,68 +686,6 @@ class StepTimeout(RuntimeError):
 DRY_RUN_COMPUTE = None
 
 
-def dry_run_rank(a):
-    """One rank of `python <shim> --gpus N --cpu-dry-run`: everything of the N > 1 path that is not the GPU -- the
-    self-launcher's environment, the gloo group, slab_bounds, the poisoned halos and the torch.distributed exchange of
-    patch.SlabStepper, the first-sweep verification, barriers, max over ranks, the JSON line, the teardown."""
-    import torch
-    import torch.distributed as dist
-    import __graft_entry__ as g
-    if DRY_RUN_COMPUTE is None:
-        raise SystemExit("bench.py --cpu-dry-run: no compute callable injected (bench.DRY_RUN_COMPUTE); the product has no CPU path")
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    if os.environ.get("AMT_BENCH_TEST_DIE_RANK") == str(rank):     # tests/test_bench_dry_run.py: a rank that dies before the group forms
-        print(f"rank {rank} exiting with code 7 for the teardown test", file=sys.stderr, flush=True)
-        os._exit(7)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(60.0, a.comm_timeout)))
-    pkg = g.load_package()
-    S = pkg.synth
-    dtype = np.float64 if a.dtype == "f64" else np.float32
-    dims = (a.ni, a.nk, a.nj)
-    gb = S.domain_bounds(*dims, aligned=True, align_elems=a.align_elems)
-    sb = S.slab_bounds(gb, rank, world)
-    host = S.make_patch(sb, pkg.GridConfig(), dtype=dtype, seed=a.seed, global_dims=dims)
-    arrays = {k: torch.from_numpy(v) for k, v in host.arrays.items()}
-    if rank < world - 1:
-        for name in S.HALO_FROM_ABOVE:
-            arrays[name][-1].fill_(float("nan"))
-    if rank > 0:
-        arrays["t_1"][0].fill_(float("nan"))
-    patch = S.Patch(sb, host.config, arrays, host.rdx, host.rdy, host.dts, host.epssm, dims)
-    stepper = pkg.patch.SlabStepper(patch, rank, world, DRY_RUN_COMPUTE)
-    dist.barrier()
-    stepper.step()
-    oracle = g.load_oracle()                                     # the checker, as in the GPU path
-    verified, why = verify_first_sweep(pkg, oracle, patch, gb, dims, dtype, a.seed, (sb.jts, sb.jte))
-    for _ in range(max(a.warmup - 1, 0)):
-        stepper.step()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        stepper.step()
-    dist.barrier()
-    wall = time.perf_counter() - t0
-    t = torch.tensor([wall, 1.0 if verified else 0.0], dtype=torch.float64)
-    tmax, tmin = t.clone(), t.clone()
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-    if rank == 0:
-        print(json.dumps({"dry_run": True, "note": "CPU plumbing run of the N > 1 path with an injected compute callable: not a measurement",
-                          "n_gpus": world, "ranks_seen": dist.get_world_size(), "steps": a.steps, "warmup": a.warmup,
-                          "ms_per_step": round(float(tmax[0]) * 1e3 / max(a.steps, 1), 4), "verified_vs_oracle": bool(tmin[1] > 0.5),
-                          "verify_message": why or None, "scaling": "strong",
-                          "config": {"workload": f"advance_mu_t {a.ni}x{a.nk}x{a.nj} {a.dtype}, {world} j-slab(s)",
-                                     "rows_per_rank": [S.slab_bounds(gb, r, world).jte - S.slab_bounds(gb, r, world).jts + 1 for r in range(world)],
-                                     "halo_transport": "gloo (CPU tensors)", "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep()},
-                          "launched_by": "bench.py self-launch" if os.environ.get("AMT_BENCH_SELF_LAUNCHED") else "external launcher"}), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
-    if not bool(tmin[1] > 0.5):
-        raise SystemExit(3)
-
-
 def watchdog(fn, seconds, what):
     """Run fn() on a helper thread and wait at most `seconds`: the calls that can block for ever inside RCCL
     (ncclCommInitRank while a peer never arrives, the first send/recv of a connection) must not take the
@@ -752,13 +715,33 @@ def die(rank, code, msg):
     os._exit(code)                               # not SystemExit: a helper thread may still be blocked inside RCCL
 
 
+def start_cpu_prebuild():
+    """The -march=native CPU libraries of THIS machine (oracle/_native/<cpu>/: the Fortran CPU path in both precisions, the two
+    harnesses) are compiled by a child of their own, started before anything else of the run and joined in front of the CPU leg:
+    on a cold box that is 20-45 s of amdflang / amdclang / gcc, which now runs BESIDE the GPU part of the line (compilers on a few
+    host cores; the timed region is 20 launches and their events) instead of in front of the CPU leg, and costs nothing where the
+    directory is already there."""
+    import subprocess
+    worker = str(ROOT / "oracle" / "cpu_bench.py")
+    try:
+        p = subprocess.Popen([sys.executable, worker, "--prebuild"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except OSError:
+        return None
+    return {"proc": p, "t0": time.perf_counter()}
+
+
 def run_rank(a):
+    """N = 1 (the driver's headline line), and the in-process bring-up modes of N > 1 (--backend gloo: halo rows staged through the
+    host, ranks may share a GPU; --stepper torch: torch.distributed P2P ops over RCCL).  The default N > 1 path is supervise()."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if os.environ.get("AMT_BENCH_TEST_HANG"):      # tests/test_bench_contract.py: a rank that never comes back
         print(f"rank {rank} pid {os.getpid()} hanging for the teardown test", file=sys.stderr, flush=True)
         time.sleep(float(os.environ["AMT_BENCH_TEST_HANG"]))
         raise SystemExit(0)
+    if a.traffic_layouts:
+        return traffic_child(a)
+    prebuild = start_cpu_prebuild() if world == 1 and not a.no_cpu_baseline else None
     smi_idle = gpu_state_smi() if rank == 0 and not a.no_box_probe else None     # before anything touches the GPU
     import torch
     import torch.distributed as dist
@@ -766,31 +749,25 @@ def run_rank(a):
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     a.gpus = world
-    if world > 1 and a.transport == "ipc":
-        os.environ["AMT_SLAB_TRANSPORT"] = "ipc"       # also makes amt_comm_unique_id independent of RCCL
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     ndev = torch.cuda.device_count()
     if a.backend == "gloo":
-        a.stepper = "torch"                        # bring-up mode: host-staged rows, ranks may share a GPU
-        local_rank = local_rank % ndev
+        local_rank = local_rank % ndev             # bring-up mode: host-staged rows, ranks may share a GPU
     elif world > 1 and a.share_gpu:
-        local_rank = local_rank % ndev             # failure-path bring-up: RCCL will refuse two ranks on one device
+        local_rank = local_rank % ndev
     elif world > 1 and local_rank >= ndev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible (RCCL needs one "
                          "GPU per rank; --backend gloo shares a GPU for bring-up)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    native = world > 1 and a.stepper == "native"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         pg_timeout = datetime.timedelta(seconds=max(60.0, 2 * a.comm_timeout + 60.0))     # never the 30-minute default
-        if a.backend == "nccl" and not native:
+        if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=pg_timeout)
         else:
-            # native stepper: RCCL lives inside the C++ runtime; torch.distributed (gloo, host side)
-            # only carries the communicator id, the barriers and the max over ranks of the timings
             dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
 
     pkg = g.load_package()
@@ -804,10 +781,10 @@ def run_rank(a):
     gb = gb.replace(ime=gb.ime + a.idim_extra)
     sb = S.slab_bounds(gb, rank, world)
     cfg = pkg.GridConfig()
+    sides = S.neighbour_sides(0, rank, 1, world)
 
     # every launch, copy and event of this rank goes to ONE stream (torch's current one)
-    main_stream = torch.cuda.Stream(device=device) if native else torch.cuda.current_stream(device)
-    torch.cuda.set_stream(main_stream)
+    main_stream = torch.cuda.current_stream(device)
     # The state is allocated by the PRODUCT: amt_domain_create, the call a Fortran or C host makes once, with its default
     # placement sampling (AMT_DOMAIN_PLACEMENT_TRIES allocations of the state, the fastest kept: the sweep time depends on which
     # physical pages the driver hands out, profiles/r05_placement.md).  The tensors below VIEW those arrays: `value` is what a
@@ -824,85 +801,15 @@ def run_rank(a):
         except Exception as e:  # noqa: BLE001
             ceilings = {"error": f"{type(e).__name__}: {e}"}
 
-    def poison_halos():
-        # only a working exchange gives the right answer
-        if world > 1:
-            if rank < world - 1:
-                for name in S.HALO_FROM_ABOVE:
-                    dev.arrays[name][-1].fill_(float("nan"))
-            if rank > 0:
-                dev.arrays["t_1"][0].fill_(float("nan"))
-
-    poison_halos()
+    S.poison_halos(dev, sides)                 # only a working exchange gives the right answer (nothing for a world of one)
     torch.cuda.synchronize()
-    ranks_seen = 1
-    native_error, p2p_group = None, None
-    if native:
-        # phase 1, no collective: every rank must be able to open RCCL; agree before anyone blocks
-        # in ncclCommInitRank waiting for a rank that cannot come
-        err = ""
-        try:
-            uid = [pkg.patch.NativeSlabStepper.comm_unique_id() if rank == 0 else None]
-            if rank != 0:
-                pkg.patch.NativeSlabStepper.comm_unique_id()
-        except pkg.AmtError as e:
-            err, uid = str(e), [None]
-        flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() < 0.5:
-            raise SystemExit(f"rank {rank}: no communicator id for the native stepper ({a.transport}): {err or 'another rank failed'}")
-        dist.broadcast_object_list(uid, src=0)
-        # phase 2, collective (ncclCommInitRank).  It runs on a helper thread under a watchdog, so that every
-        # rank reaches the agreement below within --comm-timeout whatever its peers do.  Outcomes, worst over ranks:
-        #   every rank has its communicator            -> the native stepper is timed;
-        #   clean failure (an error code) somewhere   -> all ranks go on with the torch.distributed stepper and
-        #                                                 the line SAYS so (a cross-check measurement beats none);
-        #   a rank still blocked inside RCCL           -> every rank ends itself, non-zero, with what it knows.
-        def where():
-            return (f"rank {rank}/{world} device {local_rank} MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} "
-                    f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG', 'unset')} HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}")
-        stepper, state = None, 2
-        try:
-            stepper = watchdog(lambda: pkg.patch.NativeSlabStepper(dev, rank, world, uid[0], stream=main_stream,
-                                                                   overlap=not a.no_overlap, variant=a.variant,
-                                                                   transport=a.transport),
-                               a.comm_timeout, "amt_slab_create (ncclCommInitRank)" if a.transport == "rccl" else "amt_slab_create (IPC set-up)")
-        except StepTimeout as e:
-            native_error, state = f"{e}; {where()}", 0
-        except pkg.AmtError as e:
-            native_error, state = f"{e}; {where()}", 1
-        flag = torch.tensor([float(state)], dtype=torch.float64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() < 0.5:
-            die(rank, 5, native_error or "another rank is blocked in ncclCommInitRank; ending this rank too")
-        if flag.item() < 1.5:
-            if stepper is not None:
-                try:
-                    watchdog(stepper.close, 20.0, "amt_slab_destroy")
-                except Exception:  # noqa: BLE001
-                    pass
-            native, stepper = False, None
-            native_error = native_error or "the native stepper could not be created on another rank"
-            print(f"bench.py rank {rank}: native stepper unavailable ({native_error}); falling back to --stepper torch",
-                  file=sys.stderr, flush=True)
-            import datetime
-            try:
-                p2p_group = watchdog(lambda: dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=a.comm_timeout)),
-                                     a.comm_timeout + 10, "torch.distributed nccl group for the fallback stepper")
-            except Exception as e:  # noqa: BLE001
-                die(rank, 5, f"no RCCL path at all: native: {native_error}; torch.distributed: {type(e).__name__}: {e}")
-        else:
-            ranks_seen = stepper.comm_info()[1]
-    if not native:
-        stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap, group=p2p_group,
-                                        variant=a.variant, stage_through_host=(a.backend == "gloo"))
-        if world > 1:
-            ranks_seen = dist.get_world_size()
+    stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap,
+                                    variant=a.variant, stage_through_host=(a.backend == "gloo"))
+    ranks_seen = dist.get_world_size() if world > 1 else 1
     torch.cuda.synchronize()
     if world > 1:
         # establish the RCCL point-to-point connections outside any timed or verified step (the
-        # first send/recv between two ranks builds their channels, which takes seconds);
-        # the inputs are static, so an extra exchange changes nothing
+        # first send/recv between two ranks builds their channels, which takes seconds)
         def first_exchange():
             torch.cuda.set_device(device)              # the helper thread has its own current device
             stepper.exchange_halos()
@@ -910,13 +817,14 @@ def run_rank(a):
         try:
             watchdog(first_exchange, a.comm_timeout, "first halo exchange (RCCL connection set-up)")
         except Exception as e:  # noqa: BLE001  (a rank that cannot exchange must not leave its peers waiting for ever)
-            die(rank, 6, f"{type(e).__name__}: {e}; rank {rank}/{world} device {local_rank}, stepper "
-                         f"{'native' if native else 'torch'}, neighbours {[r for r in (rank - 1, rank + 1) if 0 <= r < world]}")
-        poison_halos()                             # the verification must see the in-step exchange
+            die(rank, 6, f"{type(e).__name__}: {e}; rank {rank}/{world} device {local_rank}, torch stepper, "
+                         f"neighbours {[r for r in (rank - 1, rank + 1) if 0 <= r < world]}")
+        S.poison_halos(dev, sides)                 # the verification must see the in-step exchange
         torch.cuda.synchronize()
         dist.barrier()
 
     verified, why = None, ""
+    verified_later = None
     fp32_err = None
     oracle = None
     warm_done = 0
@@ -925,22 +833,31 @@ def run_rank(a):
         stepper.step()
         warm_done = 1
         torch.cuda.synchronize()
-        verified, why = verify_first_sweep(pkg, oracle, dev, gb, dims, dtype, a.seed, (sb.jts, sb.jte))
+        verified, why = verify_sweeps(pkg, oracle, dev, gb, dims, dtype, a.seed, (sb.jts, sb.jte), 1)
         if a.dtype == "f32" and rank == 0:
             fp32_err = fp32_error_vs_fp64(pkg, oracle, dev, gb, dims, a.seed, (sb.jts, sb.jte))
+        if world > 1:
+            # a second verified sweep on NEW values of the exchanged fields and re-poisoned halo rows: an exchange that delivers
+            # once and never again passes the first check and fails this one
+            S.refresh_exchanged_inputs(dev, a.seed, 1)
+            S.poison_halos(dev, sides)
+            stepper.step()
+            warm_done = 2
+            torch.cuda.synchronize()
+            verified_later, why2 = verify_sweeps(pkg, oracle, dev, gb, dims, dtype, a.seed, (sb.jts, sb.jte), 2)
+            why = why or why2
+            verified = bool(verified and verified_later)
     clock_ramp = None
     if not a.no_box_probe:
         try:
             clock_ramp = ramp_clocks(pkg, main_stream, dev.arrays["u"])
         except Exception as e:  # noqa: BLE001
             clock_ramp = {"error": f"{type(e).__name__}: {e}"}
-    for _ in range(a.warmup - warm_done):
+    for _ in range(max(a.warmup - warm_done, 0)):
         stepper.step()
 
     def fence():
         torch.cuda.synchronize()
-        if native:
-            stepper.sync()                         # also reports a device-side wait for a neighbour that gave up (IPC transport)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
@@ -997,6 +914,7 @@ def run_rank(a):
                                       f"not re-measured in this run)")
             except Exception:
                 traffic = None
+        row_bytes = gb.idim * itemsize
         out = {
             "metric": "advance_mu_t grid-cells/sec (Mcells/s) + achieved HBM GB/s",
             "value": round(value, 2),
@@ -1015,22 +933,20 @@ def run_rank(a):
             "config": {"workload": f"advance_mu_t {a.ni}x{a.nk}x{a.nj} (i,k,j) {a.dtype}, "
                                    f"{world} j-slab(s), one-row halo exchange per sweep",
                        "ni": a.ni, "nk": a.nk, "nj": a.nj, "variant": a.variant,
+                       # the memory layout of the timed state: WRF's (ims:ime, kms:kme, jms:jme), i fastest; `aligned` = the i extent is
+                       # padded so that rows are whole 128-byte lines with i = its on a line boundary (a choice of ims:ime, which a WRF
+                       # build makes).  WRF's own unpadded extents are timed beside it: `wrf_rows` below.
+                       "idim": gb.idim, "kdim": gb.kdim, "jdim": gb.jdim, "ims": gb.ims, "ime": gb.ime,
+                       "row_bytes": row_bytes, "row_bytes_mod_128": row_bytes % 128,
+                       "aligned": bool(row_bytes % 128 == 0 and ((gb.its - gb.ims) * itemsize) % 128 == 0),
                        "halo_overlap": (not a.no_overlap) if world > 1 else None,
-                       "halo_transport": ((stepper.transport() if native else "rccl") if a.backend == "nccl"
-                                          else "gloo-host-staged (bring-up)") if world > 1 else None,
+                       "halo_transport": ("rccl" if a.backend == "nccl" else "gloo-host-staged (bring-up)") if world > 1 else None,
                        "ranks_share_a_device": bool(world > 1 and world > ndev),
-                       "halo_pull": (stepper.pull_mode() or None) if native else None,
-                       "halo_schedule": (("host-waited: post, interior on its own, pull + boundary rows behind it" if os.environ.get("AMT_IPC_HOST_WAIT", "1") != "0"
-                                          else "device-waited: waiting kernel first, interior beside it") if native and a.transport == "ipc" and not a.no_overlap
-                                         else ("exchange beside the interior (2 rounds unless --beside-rounds)" if not a.no_overlap else "no overlap")) if world > 1 else None,
-                       "interior_plan": {"beside_rounds": a.beside_rounds or 2, "beside_reserve_cus": a.beside_reserve} if world > 1 else None,
                        "halo_bytes_per_rank_per_sweep": stepper.halo_bytes_per_sweep(),
                        "placement_probe_ms": probe_ms,
                        "kernel": pkg.load_library().amt_march_last_kernel().decode()},
-            "stepper": ((f"native amt_slab_* (C++ runtime, {'ncclSend/ncclRecv' if a.transport == 'rccl' else 'IPC peer copies + mailbox'})") if native else
-                        "torch.distributed P2P (patch.SlabStepper)") if world > 1 else "single launch per sweep",
+            "stepper": "torch.distributed P2P (patch.SlabStepper)" if world > 1 else "single launch per sweep",
             "ranks_seen": ranks_seen,
-            "native_stepper_error": native_error,
             "rank_ms_per_step_min_max": [round(x, 4) for x in rank_ms],
             "launched_by": "bench.py self-launch" if os.environ.get("AMT_BENCH_SELF_LAUNCHED") else
                            ("external launcher" if world > 1 else "direct"),
@@ -1042,9 +958,8 @@ def run_rank(a):
                          "aggregate_GBps": round(abytes / ev_per_step_s / 1e9, 1)},
             "verified_vs_oracle": verified,
         }
-        if world > 1 and native and a.transport == "rccl":
-            out["faster_alternative"] = ("--transport ipc: the RCCL-free transport with its host-waited schedule (one rank of 8 in loopback: bare "
-                                         "launch + 2.3 %, flat to 1.5 ms of neighbour lateness; RCCL + 6 % and half the lateness), profiles/r05_slab_ab.md")
+        if world > 1:
+            out["verified_later_sweep_after_new_inputs"] = verified_later
         if world > 1 and world > ndev:
             out["note"] = (f"{world} ranks share {ndev} device(s): a correctness run of the whole N > 1 path (slabs, halo exchange, "
                            "verification, reductions); `value` is NOT a scaling measurement")
@@ -1093,13 +1008,25 @@ def run_rank(a):
             out["fp32_vs_fp64_oracle"] = {"max_abs_err_over_field_scale": float(f"{fp32_err:.3e}"),
                                           "stated_tolerance": 2e-5,
                                           "within_tolerance": bool(fp32_err <= 2e-5)}
+        wrf = None
+        if world == 1:
+            del stepper, dev
+            torch.cuda.empty_cache()
+            # WRF's own unpadded memory extents (ims:ime = 0:NI+1: rows of NI+2 elements, 16 bytes past a line for 4098 x fp64), in the
+            # same run on the same box: the state re-created through amt_domain_create like the headline's, 2 + N sweeps
+            if a.wrf_rows_steps > 0 and a.align_elems != 1:
+                try:
+                    wrf = time_wrf_rows(a, pkg, device, dtype, abytes)
+                except Exception as e:  # noqa: BLE001
+                    wrf = {"error": f"{type(e).__name__}: {e}"}
+                out["wrf_rows"] = wrf
         if world == 1 and not a.no_traffic:
-            # same-run, same-box HBM traffic: this process gives its arrays back first
+            # same-run, same-box HBM traffic: this process has given its arrays back
             rf = out["roofline"]
             try:
-                del stepper, dev
-                torch.cuda.empty_cache()
-                rd_m, wr_m, note = measure_traffic(a)
+                layouts = [a.align_elems] + ([1] if wrf and "error" not in wrf else [])
+                res, note = measure_traffic(a, layouts)
+                rd_m, wr_m = res[a.align_elems]
                 rf["traffic_recorded"], rf["traffic_recorded_source"] = rf.get("traffic"), rf.get("traffic_source")
                 rf["traffic"], rf["traffic_source"] = int(rd_m + wr_m), note
                 rf["traffic_read_bytes"], rf["traffic_write_bytes"] = int(rd_m), int(wr_m)
@@ -1111,33 +1038,630 @@ def run_rank(a):
                     rf["box_mixed_ceiling_ms"] = round(mixed_ms, 4)
                     rf["frac_of_box_copy"] = round((rd_m + wr_m) / ev_per_step_s / 1e9 / cp, 4)
                     rf["frac_of_box_mixed"] = round(mixed_ms / (ev_per_step_s * 1e3), 4)
+                if 1 in res and wrf and "error" not in wrf:
+                    rd_w, wr_w = res[1]
+                    wrf.update(traffic=int(rd_w + wr_w), traffic_read_bytes=int(rd_w), traffic_write_bytes=int(wr_w),
+                               traffic_over_algorithmic=round((rd_w + wr_w) / abytes, 4))
             except Exception as e:  # noqa: BLE001  (the recorded value stays, and the line says why)
                 rf["traffic_same_run_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(dims, a.dtype, a.seed, a.cpu_rows, a.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(dims, a.dtype, a.seed, a.cpu_rows, a.cpu_seconds, prebuild=prebuild)
             except Exception as e:  # noqa: BLE001  (the ancillary leg never costs the GPU line)
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
 
     if world > 1:
         dist.barrier()
-        if native:
-            stepper.close()
         dist.destroy_process_group()
     if verified is False:
         raise SystemExit(3)
 
 
+def time_wrf_rows(a, pkg, device, dtype, abytes):
+    """The same sweep on WRF's own memory extents -- ims:ime = 0:NI+1, no padding: rows of NI+2 elements -- on this box, in this
+    run: state from amt_domain_create (placement sampling as for the headline), 2 warm-up + --wrf-rows-steps timed sweeps."""
+    import torch
+    S = pkg.synth
+    gb = S.domain_bounds(a.ni, a.nk, a.nj, aligned=True, align_elems=1)
+    itemsize = np.dtype(dtype).itemsize
+    dev = S.make_patch(gb, pkg.GridConfig(), dtype=dtype, seed=a.seed, global_dims=(a.ni, a.nk, a.nj), device=device, native_domain=True)
+    probe = dev.owner.placement_ms() or None
+    call = pkg.advance_mu_t.bind(*dev.args(), variant=a.variant)
+    for _ in range(2):
+        call()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.wrf_rows_steps + 1)]
+    stream = torch.cuda.current_stream(device)
+    ev[0].record(stream)
+    for k in range(a.wrf_rows_steps):
+        call()
+        ev[k + 1].record(stream)
+    torch.cuda.synchronize()
+    per = [ev[k].elapsed_time(ev[k + 1]) for k in range(a.wrf_rows_steps)]
+    ms = ev[0].elapsed_time(ev[-1]) / a.wrf_rows_steps
+    kernel = pkg.load_library().amt_march_last_kernel().decode()
+    del call, dev
+    torch.cuda.empty_cache()
+    return {"layout": "WRF's own memory extents ims:ime = 0:NI+1 (bench.py --align-elems 1): no padding",
+            "idim": gb.idim, "row_bytes": gb.idim * itemsize, "row_bytes_mod_128": (gb.idim * itemsize) % 128,
+            "steps": a.wrf_rows_steps, "ms_per_step": round(ms, 4), "ms_per_step_median": round(float(np.median(per)), 4),
+            "frac": round(abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "achieved_GBps": round(abytes / (ms * 1e-3) / 1e9, 1),
+            "placement_probe_ms": probe, "kernel": kernel}
+
+
+# =====================================================================================================================
+# N > 1: supervisors and rungs.
+#
+# The process a launcher starts per rank (bench.py's own self-launch, or torch.distributed.run) is a SUPERVISOR: it never
+# touches a GPU.  The supervisors hold a gloo group among themselves (host side only: agreement, gathering the records) and
+# walk a LADDER of rungs; for every rung each supervisor starts a FRESH child process of this script (`--rung-child <name>`)
+# that sets its device, builds its slab, creates the stepper and measures -- and that the supervisor ends, by its exact pid,
+# if it does not come back within --rung-timeout.  Whatever a transport does on first contact with real hardware (an
+# ncclCommInitRank that never returns, a hipIpcOpenMemHandle that refuses, a kernel that waits for ever) costs one rung on
+# every rank, never the launch, and no process that has initialised the GPU is ever re-used or re-exec'ed.  The children of a
+# rung need no torch.distributed: the communicator id travels through the library's file rendezvous and the barriers / max
+# over ranks through amt_slab_barrier / amt_slab_max -- exactly what a Fortran host without MPI uses.
+#
+#   preflight        device count, peer-access matrix, librccl, /dev/shm  (never fatal by itself: recorded)
+#   rccl             native stepper, ncclSend/ncclRecv, device-waited schedule       } --transport both: both are timed
+#   ipc              native stepper, IPC mailbox + pulls, host-waited schedule       } and verified, each on fresh processes
+#   torch-rccl       torch.distributed P2P stepper over RCCL: only if no native rung succeeded
+#
+# `value` is north_star's transport (RCCL) when its rung succeeded, else the IPC rung's, else torch's; every rung's outcome
+# is in the line (`ladder`, `transports`).  advance_mu_t_no_async.cu:329-357 is what this replaces: the reference launches and
+# synchronises its devices from one host thread and has no failure path but exit(1).
+# =====================================================================================================================
+RUNG_FAIL_EXIT = 21          # a rung's child that failed cleanly (its JSON record says why)
+
+
+def verify_sweeps(pkg, oracle, dev, gb, dims, dtype, seed, rank_rows, sweeps=1):
+    """After exactly `sweeps` sweeps from fresh inputs -- sweep s > 0 having run on the exchanged inputs of seed + s
+    (synth.refresh_exchanged_inputs) -- recompute a few 3-row j-slabs with the oracle from regenerated inputs, the same
+    refills between its sweeps, and compare bit for bit (size-independent parity check; the slabs sit on this rank's first
+    and last rows, where only a halo row that arrived in THIS sweep gives the right bits)."""
+    S = pkg.synth
+    b = dev.bounds
+    jlo_own, jhi_own = rank_rows
+    cand = sorted({jlo_own, max(jlo_own, jhi_own - 2), (jlo_own + jhi_own) // 2})
+    for jlo in cand:
+        jhi = min(jlo + 2, jhi_own)
+        sb = gb.replace(jms=jlo - 1, jme=jhi + 1, jts=jlo, jte=jhi)
+        want = S.make_patch(sb, dev.config, dtype=dtype, seed=seed, global_dims=dims)
+        for s in range(sweeps):
+            if s:
+                S.refresh_exchanged_inputs(want, seed, s)
+            oracle.advance_mu_t_omp(*want.args(), nthreads=min(3, jhi - jlo + 1))
+        for n in S.OUTPUTS:
+            got = dev.arrays[n][jlo - b.jms: jhi + 1 - b.jms]
+            got = got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)
+            w = want.arrays[n][1: 1 + (jhi - jlo + 1)]
+            if not np.array_equal(np.ascontiguousarray(got).view(np.uint8), w.view(np.uint8)):
+                return False, f"rows {jlo}..{jhi} of {n} differ from the oracle after sweep {sweeps}"
+    return True, ""
+
+
+RUNG_RECORD_MARK = "AMT_RUNG_RECORD "
+
+
+def _emit(rec, code=0):
+    """A rung child's one record: a line of its own behind a marker (libraries write to the same stdout -- RCCL's warnings do not
+    always end their lines), which its supervisor looks for from the end; then exit."""
+    sys.stdout.write("\n" + RUNG_RECORD_MARK + json.dumps(rec) + "\n")
+    sys.stdout.flush()
+    os._exit(code)                      # not SystemExit: a helper thread may still sit inside RCCL
+
+
+def _injected_outcome(kind, rank):
+    """tests/test_bench_dry_run.py: AMT_BENCH_TEST_RUNG_<KIND>=refuse|hang|open_fails[:rank] makes this rung's child (of that
+    rank, default every rank) fail cleanly at set-up, never come back, or fail like a refused IPC handle."""
+    spec = os.environ.get("AMT_BENCH_TEST_RUNG_" + kind.upper().replace("-", "_"), "")
+    if not spec:
+        return None
+    what, _, who = spec.partition(":")
+    if who and int(who) != rank:
+        return None
+    return what
+
+
+def preflight_child(a):
+    """What the node looks like before any transport is tried: devices, peer access, librccl, /dev/shm.  Touches the GPU
+    (a fresh process per rank, under the supervisor's timeout)."""
+    import ctypes
+    rank = int(os.environ.get("RANK", "0"))
+    rec = {"rung": "preflight", "rank": rank, "ok": True}
+    if a.cpu_dry_run:
+        rec.update(devices=0, dry_run=True)
+        _emit(rec)
+    import torch
+    if not torch.cuda.is_available():
+        rec.update(ok=False, error="bench.py needs a GPU (there is no CPU fallback for the product path)")
+        print(rec["error"], file=sys.stderr, flush=True)
+        _emit(rec, RUNG_FAIL_EXIT)
+    ndev = torch.cuda.device_count()
+    rec["devices"] = ndev
+    rec["device_name"] = torch.cuda.get_device_name(0)
+    if rank == 0:
+        try:
+            rec["peer_access"] = [[1 if i == j else int(torch.cuda.can_device_access_peer(i, j)) for j in range(ndev)] for i in range(ndev)]
+        except Exception as e:  # noqa: BLE001
+            rec["peer_access"] = f"unavailable ({type(e).__name__}: {e})"
+    try:
+        lib = None
+        for name in (os.environ.get("AMT_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+            if name:
+                try:
+                    lib = ctypes.CDLL(name)
+                    break
+                except OSError:
+                    continue
+        if lib is None:
+            raise OSError("librccl not found")
+        v = ctypes.c_int(0)
+        lib.ncclGetVersion(ctypes.byref(v))
+        rec["rccl"] = {"loadable": True, "version": v.value}
+    except Exception as e:  # noqa: BLE001
+        rec["rccl"] = {"loadable": False, "error": f"{type(e).__name__}: {e}"}
+    try:
+        st = os.statvfs("/dev/shm")
+        rec["dev_shm_free_MiB"] = int(st.f_bavail * st.f_frsize / 2**20)
+    except OSError as e:
+        rec["dev_shm_free_MiB"] = f"unavailable ({e})"
+    rec["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    _emit(rec)
+
+
+def rung_child(a):
+    """One rank's child of one rung: everything that touches the GPU (or, with --cpu-dry-run, the CPU stand-in with the compute
+    callable the test shim injects).  Prints ONE JSON record and exits 0, or RUNG_FAIL_EXIT with the error in the record."""
+    kind = a.rung_child
+    if kind == "preflight":
+        return preflight_child(a)
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    launch_dir = os.environ["AMT_BENCH_DIR"]
+    rec = {"rung": kind, "rank": rank, "ok": False}
+    injected = _injected_outcome(kind, rank)
+    if injected == "hang":
+        print(f"rank {rank} rung {kind}: hanging (injected)", file=sys.stderr, flush=True)
+        time.sleep(3600)
+    if injected in ("refuse", "open_fails"):
+        rec["error"] = ("ncclCommInitRank failed: invalid usage (injected)" if injected == "refuse"
+                        else "hipIpcOpenMemHandle of rank 1's rows failed: invalid argument (injected)")
+        _emit(rec, RUNG_FAIL_EXIT)
+
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    S = pkg.synth
+    dtype = np.float64 if a.dtype == "f64" else np.float32
+    itemsize = np.dtype(dtype).itemsize
+    dims = (a.ni, a.nk, a.nj)
+    gb = S.domain_bounds(*dims, aligned=True, align_elems=a.align_elems)
+    gb = gb.replace(ime=gb.ime + a.idim_extra)
+    sb = S.slab_bounds(gb, rank, world)
+    cfg = pkg.GridConfig()
+    sides = S.neighbour_sides(0, rank, 1, world)
+    dry = a.cpu_dry_run
+    transport = {"rccl": "rccl", "ipc": "ipc"}.get(kind)
+    dist = None
+
+    def fail(msg, code=RUNG_FAIL_EXIT):
+        rec["error"] = msg
+        print(f"bench.py rank {rank} rung {kind}: {msg}", file=sys.stderr, flush=True)
+        _emit(rec, code)
+
+    # ---- the state and the stepper ------------------------------------------------------------------------------------
+    native = transport is not None and not dry
+    if dry:
+        if DRY_RUN_COMPUTE is None:
+            fail("bench.py --cpu-dry-run: no compute callable injected (bench.DRY_RUN_COMPUTE); the product has no CPU path", 2)
+        import datetime
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method=f"file://{launch_dir}/store_{kind}", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=max(30.0, a.comm_timeout)))
+        host = S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims)
+        dev = S.Patch(sb, host.config, {k: torch.from_numpy(v) for k, v in host.arrays.items()}, host.rdx, host.rdy, host.dts, host.epssm, dims)
+        S.poison_halos(dev, sides)
+        stepper = pkg.patch.SlabStepper(dev, rank, world, DRY_RUN_COMPUTE)
+        ndev, device, main_stream = 0, None, None
+    else:
+        if not torch.cuda.is_available():
+            fail("bench.py needs a GPU (there is no CPU fallback for the product path)", 2)
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev and not a.share_gpu:
+            fail(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible (one GPU per rank; --share-gpu --transport ipc shares them)", 2)
+        local_rank = local_rank % ndev
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        if transport == "ipc":
+            os.environ["AMT_SLAB_TRANSPORT"] = "ipc"       # also makes the communicator id independent of RCCL
+        if a.beside_rounds or a.beside_reserve:
+            pkg.load_library().amt_march_set_beside(a.beside_rounds, a.beside_reserve)
+        main_stream = torch.cuda.Stream(device=device) if native else torch.cuda.current_stream(device)
+        torch.cuda.set_stream(main_stream)
+        if a.probe_placements > 0:
+            os.environ["AMT_DOMAIN_PLACEMENT_TRIES"] = str(a.probe_placements)
+        dev = S.make_patch(sb, cfg, dtype=dtype, seed=a.seed, global_dims=dims, device=device, native_domain=True)
+        rec["placement_probe_ms"] = dev.owner.placement_ms() or None
+        S.poison_halos(dev, sides)                          # only a working exchange gives the right answer
+        torch.cuda.synchronize()
+        if native:
+            import ctypes
+            uid = (ctypes.c_char * 128)()
+            try:
+                pkg.lib.check(pkg.load_library().amt_comm_rendezvous_file(f"{launch_dir}/uid_{kind}".encode(), 0, rank, world,
+                                                                          float(a.comm_timeout), uid))
+                stepper = pkg.patch.NativeSlabStepper(dev, rank, world, bytes(uid), stream=main_stream, overlap=not a.no_overlap,
+                                                      variant=a.variant, transport=transport)
+            except pkg.AmtError as e:
+                fail(f"{e}; rank {rank}/{world} device {local_rank} NCCL_DEBUG={os.environ.get('NCCL_DEBUG', 'unset')} "
+                     f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}")
+        else:                                               # torch-rccl: torch.distributed P2P ops around the same launches
+            import datetime
+            import torch.distributed as dist
+            try:
+                dist.init_process_group("nccl", init_method=f"file://{launch_dir}/store_{kind}", rank=rank, world_size=world,
+                                        device_id=device, timeout=datetime.timedelta(seconds=max(60.0, a.comm_timeout)))
+            except Exception as e:  # noqa: BLE001
+                fail(f"torch.distributed nccl group: {type(e).__name__}: {e}")
+            stepper = pkg.patch.SlabStepper(dev, rank, world, pkg.advance_mu_t, overlap=not a.no_overlap, variant=a.variant)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+        if native:
+            stepper.sync()                 # also reports a device-side wait for a neighbour that gave up (IPC transport)
+
+    def barrier():
+        sync()
+        if native:
+            pkg.lib.check(stepper.L.amt_slab_barrier(stepper._slab))
+        else:
+            dist.barrier()
+        if not dry:
+            torch.cuda.synchronize()
+
+    def rank_max(x):
+        if native:
+            import ctypes
+            v = ctypes.c_double(float(x))
+            pkg.lib.check(stepper.L.amt_slab_max(stepper._slab, ctypes.byref(v)))
+            return v.value
+        t = torch.tensor([float(x)], dtype=torch.float64, device=device if (dist.get_backend() == "nccl") else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def step(n=1):
+        if native:
+            stepper.step(n)
+        else:
+            for _ in range(n):
+                stepper.step()
+
+    def next_inputs(sweep):
+        """new values in the fields that cross a slab boundary (the stand-in for advance_uv) and NaN in the halo rows again"""
+        if native:
+            stepper.next_substep_inputs(a.seed, sweep)
+        else:
+            S.refresh_exchanged_inputs(dev, a.seed, sweep)
+            S.poison_halos(dev, sides)
+
+    try:
+        rec["ranks_seen"] = stepper.comm_info()[1] if native else dist.get_world_size()
+        # the point-to-point connections are built by the first exchange, which takes seconds: outside anything timed or
+        # verified (the inputs are what they are: an extra exchange changes nothing; the halos are poisoned again after it)
+        stepper.exchange_halos()
+        sync()
+        S.poison_halos(dev, sides)
+        barrier()
+        # ---- verification: sweep 1 from poisoned halos, and sweep 2 after NEW inputs and re-poisoned halos (an exchange that
+        # delivers once and never again passes the first check and fails the second)
+        verified_first = verified_later = None
+        why = ""
+        warm_done = 0
+        if a.warmup > 0 and not a.no_verify:
+            oracle = g.load_oracle()
+            step()
+            sync()
+            verified_first, why = verify_sweeps(pkg, oracle, dev, gb, dims, dtype, a.seed, (sb.jts, sb.jte), 1)
+            next_inputs(1)
+            step()
+            sync()
+            verified_later, why2 = verify_sweeps(pkg, oracle, dev, gb, dims, dtype, a.seed, (sb.jts, sb.jte), 2)
+            why = why or why2
+            warm_done = 2
+            if a.dtype == "f32" and rank == 0 and not dry:
+                rec["fp32_note"] = "fp32 vs the fp64 oracle is measured by the N = 1 line (fp32_vs_fp64_oracle)"
+        for _ in range(max(a.warmup - warm_done, 0)):
+            step()
+        # ---- the timed sweeps: barrier + synchronize on both sides, max over ranks
+        marks = []
+        if not dry:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+        barrier()
+        t0 = time.perf_counter()
+        if not dry:
+            ev0.record(main_stream)
+        for k in range(a.steps):
+            step()
+            if not dry:
+                marks[k].record(main_stream)
+        if not dry:
+            ev1.record(main_stream)
+        barrier()
+        wall = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1) if not dry else wall * 1e3
+        per_sweep = [(ev0 if k == 0 else marks[k - 1]).elapsed_time(marks[k]) for k in range(a.steps)] if not dry else []
+        rec.update(ok=True, wall_s=wall, wall_s_max_over_ranks=rank_max(wall), event_ms=ev_ms,
+                   per_sweep_ms=[round(x, 3) for x in per_sweep] if len(per_sweep) <= 100 else None,
+                   verified_first_sweep=verified_first, verified_later_sweep=verified_later, verify_message=why or None,
+                   rows=[sb.jts, sb.jte], halo_bytes_per_sweep=stepper.halo_bytes_per_sweep(),
+                   transport=(stepper.transport() if native else ("gloo (CPU tensors)" if dry else "rccl")),
+                   pull=(stepper.pull_mode() or None) if native else None,
+                   stepper=("native amt_slab_*" if native else "torch.distributed P2P (patch.SlabStepper)"),
+                   kernel=None if dry else pkg.load_library().amt_march_last_kernel().decode(),
+                   devices_visible=ndev, device=None if dry else local_rank)
+        if verified_first is False or verified_later is False:
+            rec["ok"] = False
+            rec["error"] = f"results differ from the oracle: {why}"
+        barrier()
+    except Exception as e:  # noqa: BLE001  (AmtError(ERR_COMM) of a wait that gave up, an RCCL error, ...)
+        fail(f"{type(e).__name__}: {e}")
+    try:
+        if native:
+            stepper.close()
+        elif dist is not None:
+            dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+    _emit(rec, 0 if rec["ok"] else RUNG_FAIL_EXIT)
+
+
+def _set_pdeathsig():
+    """preexec of a rung child: die with the supervisor (a launcher that kills the supervisor by pid must not leave a child
+    with a GPU context behind)."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)       # PR_SET_PDEATHSIG
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def run_rung_child(a, kind, env, timeout):
+    """Start this rank's child of rung `kind`, wait at most `timeout` seconds, return its record (the last JSON line of its
+    stdout) -- or a record that says what happened instead.  The child is ended by its exact pid, never by a pattern."""
+    import subprocess
+    import threading
+    rank = int(os.environ.get("RANK", "0"))
+    argv = [sys.executable, str(Path(sys.argv[0]).resolve())] + [x for x in sys.argv[1:]] + ["--rung-child", kind]
+    t0 = time.perf_counter()
+    p = subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, preexec_fn=_set_pdeathsig)
+    err_tail = []
+
+    def pump():
+        for line in iter(p.stderr.readline, b""):
+            text = line.decode(errors="replace")
+            err_tail.append(text)
+            del err_tail[:-30]
+            sys.stderr.write(f"[{kind}] " + text)
+            sys.stderr.flush()
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    timed_out = False
+    try:
+        out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        p.kill()
+        out, _ = p.communicate()
+    th.join(timeout=2)
+    seconds = round(time.perf_counter() - t0, 1)
+    rec = None
+    text = (out or b"").decode(errors="replace")
+    at = text.rfind(RUNG_RECORD_MARK)
+    if at >= 0:
+        try:
+            rec, _ = json.JSONDecoder().raw_decode(text[at + len(RUNG_RECORD_MARK):])
+        except ValueError:
+            rec = None
+    if timed_out:
+        rec = {"rung": kind, "rank": rank, "ok": False, "timed_out": True,
+               "error": f"no return within {timeout:.0f} s (--rung-timeout): the child was ended by its pid; last stderr: "
+                        + "".join(err_tail[-3:]).strip()[-300:]}
+    elif rec is None:
+        rec = {"rung": kind, "rank": rank, "ok": False,
+               "error": f"the child exited with code {p.returncode} without a record; last stdout: {text.strip()[-200:]!r}; last stderr: "
+                        + "".join(err_tail[-5:]).strip()[-400:]}
+    elif p.returncode != 0 and rec.get("ok"):
+        rec["ok"], rec["error"] = False, f"the child exited with code {p.returncode} after reporting success"
+    rec["exit_code"], rec["seconds"] = p.returncode, seconds
+    return rec
+
+
+def supervise(a):
+    """One rank's supervisor of an N > 1 run (see the block comment above)."""
+    import datetime
+    import shutil
+    import tempfile
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    if os.environ.get("AMT_BENCH_TEST_HANG"):      # tests/test_bench_contract.py: a rank that never comes back
+        print(f"rank {rank} pid {os.getpid()} hanging for the teardown test", file=sys.stderr, flush=True)
+        time.sleep(float(os.environ["AMT_BENCH_TEST_HANG"]))
+        raise SystemExit(0)
+    if os.environ.get("AMT_BENCH_TEST_DIE_RANK") == str(rank):     # tests/test_bench_dry_run.py: a rank that dies before the group forms
+        print(f"rank {rank} exiting with code 7 for the teardown test", file=sys.stderr, flush=True)
+        os._exit(7)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=max(120.0, 2 * a.rung_timeout + 60.0)))   # never the 30-minute default
+    shared = [None]
+    if rank == 0:
+        shared[0] = {"dir": tempfile.mkdtemp(prefix="amt_bench_"), "nonce": f"{os.getpid()}-{time.time_ns()}"}
+    dist.broadcast_object_list(shared, src=0)
+    launch_dir, nonce = shared[0]["dir"], shared[0]["nonce"]
+    env = dict(os.environ, AMT_BENCH_DIR=launch_dir, AMT_RENDEZVOUS_NONCE=nonce)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+
+    def rung(kind, timeout):
+        """run this rank's child of the rung; every supervisor gets every rank's record"""
+        mine = run_rung_child(a, kind, dict(env, AMT_RENDEZVOUS_NONCE=f"{nonce}-{kind}"), timeout)
+        recs = [None] * world
+        dist.all_gather_object(recs, mine)
+        return recs
+
+    ladder = []
+    pre = rung("preflight", min(a.rung_timeout, 120.0))
+    ladder.append({"rung": "preflight", "ok": all(r["ok"] for r in pre), "seconds": max(r["seconds"] for r in pre),
+                   "errors": [f"rank {r['rank']}: {r['error']}" for r in pre if not r["ok"]] or None})
+    if not all(r["ok"] for r in pre):
+        # without a GPU (or with a rank that cannot even look at its node) there is nothing to measure
+        if rank == 0:
+            print("bench.py: preflight failed: " + "; ".join(ladder[0]["errors"]), file=sys.stderr, flush=True)
+            shutil.rmtree(launch_dir, ignore_errors=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        raise SystemExit(2)
+    kinds = {"both": ["rccl", "ipc"], "rccl": ["rccl"], "ipc": ["ipc"]}[a.transport]
+    results = {}
+    for kind in kinds:
+        recs = rung(kind, a.rung_timeout)
+        results[kind] = recs
+        ok = all(r["ok"] for r in recs)
+        ladder.append({"rung": kind, "ok": ok, "seconds": max(r["seconds"] for r in recs),
+                       "errors": [f"rank {r['rank']}: {r.get('error')}" for r in recs if not r["ok"]] or None})
+        if rank == 0 and not ok:
+            print(f"bench.py: rung {kind} failed: " + "; ".join(ladder[-1]["errors"])[:1500], file=sys.stderr, flush=True)
+    if not any(all(r["ok"] for r in results[k]) for k in kinds) and not a.cpu_dry_run and "rccl" in kinds:
+        # no native rung: the torch.distributed stepper over RCCL as the last resort (a cross-check measurement beats none)
+        recs = rung("torch-rccl", a.rung_timeout)
+        results["torch-rccl"] = recs
+        ladder.append({"rung": "torch-rccl", "ok": all(r["ok"] for r in recs), "seconds": max(r["seconds"] for r in recs),
+                       "errors": [f"rank {r['rank']}: {r.get('error')}" for r in recs if not r["ok"]] or None})
+    good = [k for k in results if all(r["ok"] for r in results[k])]
+    rc = 0
+    if rank == 0:
+        line = supervisor_line(a, world, pre, results, ladder, good)
+        print(json.dumps(line), flush=True)
+        shutil.rmtree(launch_dir, ignore_errors=True)
+    if not good:
+        rc = 5
+    elif any(r.get("verified_first_sweep") is False or r.get("verified_later_sweep") is False for k in results for r in results[k]):
+        rc = 3
+    dist.barrier()
+    dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
+
+
+def summarize_rung(a, world, recs):
+    """One transport's figures from its ranks' records (max over ranks of the wall time of the K sweeps)."""
+    cells = a.ni * a.nk * a.nj
+    itemsize = 8 if a.dtype == "f64" else 4
+    if not all(r["ok"] for r in recs):
+        return {"ok": False, "errors": [f"rank {r['rank']}: {r.get('error')}" for r in recs if not r["ok"]],
+                "timed_out_ranks": [r["rank"] for r in recs if r.get("timed_out")] or None}
+    wall = max(max(r["wall_s"], r.get("wall_s_max_over_ranks") or 0.0) for r in recs)
+    ev = [r["event_ms"] / max(a.steps, 1) for r in recs]
+    abytes = algorithmic_bytes(a.ni, a.nk, a.nj, itemsize)
+    rows = [r["rows"][1] - r["rows"][0] + 1 for r in recs]
+    per_rank_gbps = [itemsize * a.ni * n * (11 * a.nk + 14) / (ms * 1e-3) / 1e9 for n, ms in zip(rows, ev)]
+    verified = [r.get("verified_first_sweep") for r in recs] + [r.get("verified_later_sweep") for r in recs]
+    return {"ok": True,
+            "value": round(cells * a.steps / wall / 1e6, 2), "unit": "Mcells/s",
+            "ms_per_step": round(wall * 1e3 / max(a.steps, 1), 4),
+            "rank_event_ms_per_step_min_max": [round(min(ev), 4), round(max(ev), 4)],
+            "verified_first_sweep": all(r.get("verified_first_sweep") is not False for r in recs) if any(v is not None for v in verified) else None,
+            "verified_later_sweep_after_new_inputs": all(r.get("verified_later_sweep") is not False for r in recs) if any(v is not None for v in verified) else None,
+            "stepper": recs[0]["stepper"], "halo_transport": recs[0]["transport"], "halo_pull": recs[0].get("pull"),
+            "ranks_seen": min(r.get("ranks_seen") or 0 for r in recs),
+            "halo_bytes_per_rank_per_sweep": [r["halo_bytes_per_sweep"] for r in recs],
+            "per_rank_achieved_GBps": [round(x, 1) for x in per_rank_gbps],
+            "per_rank_frac_of_8TBps": [round(x / HBM_PEAK_GBS, 4) for x in per_rank_gbps],
+            "aggregate_GBps": round(abytes / (max(ev) * 1e-3) / 1e9, 1),
+            "frac_of_aggregate_peak": round(abytes / (max(ev) * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "per_sweep_ms_rank0": recs[0].get("per_sweep_ms"),
+            "kernel": recs[0].get("kernel"), "placement_probe_ms_rank0": recs[0].get("placement_probe_ms"),
+            "seconds": max(r["seconds"] for r in recs)}
+
+
+def supervisor_line(a, world, pre, results, ladder, good):
+    """The ONE JSON line of an N > 1 run (rank 0's supervisor)."""
+    S_name = {"rccl": "native amt_slab_* (C++ runtime, ncclSend/ncclRecv)", "ipc": "native amt_slab_* (C++ runtime, IPC peer copies + mailbox)",
+              "torch-rccl": "torch.distributed P2P (patch.SlabStepper)"}
+    transports = {k: summarize_rung(a, world, recs) for k, recs in results.items()}
+    head_kind = next((k for k in ("rccl", "ipc", "torch-rccl") if k in good), None)
+    head = transports.get(head_kind) if head_kind else None
+    ndev = pre[0].get("devices") or 0
+    itemsize = 8 if a.dtype == "f64" else 4
+    abytes = algorithmic_bytes(a.ni, a.nk, a.nj, itemsize)
+    out = {
+        "metric": "advance_mu_t grid-cells/sec (Mcells/s) + achieved HBM GB/s",
+        "value": head["value"] if head else None, "unit": "Mcells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": head["ms_per_step"] if head else None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic (seeded closed-form WRF-shaped fields, include/amt_synth.h)",
+        "config": {"workload": f"advance_mu_t {a.ni}x{a.nk}x{a.nj} (i,k,j) {a.dtype}, {world} j-slab(s), one-row halo exchange per sweep",
+                   "ni": a.ni, "nk": a.nk, "nj": a.nj, "variant": a.variant, "halo_overlap": not a.no_overlap,
+                   "halo_transport": head["halo_transport"] if head else None,
+                   "ranks_share_a_device": bool(ndev and world > ndev),
+                   "halo_pull": head.get("halo_pull") if head else None,
+                   "halo_schedule": None if not head or a.cpu_dry_run else
+                                    ("no overlap" if a.no_overlap else
+                                     ("host-waited: post, interior on its own, pull + boundary rows behind it" if head_kind == "ipc" and os.environ.get("AMT_IPC_HOST_WAIT", "1") != "0"
+                                      else "device-waited: exchange beside the interior (2 rounds unless --beside-rounds)")),
+                   "interior_plan": {"beside_rounds": a.beside_rounds or 2, "beside_reserve_cus": a.beside_reserve},
+                   "halo_bytes_per_rank_per_sweep": head["halo_bytes_per_rank_per_sweep"][0] if head else None,
+                   "kernel": head.get("kernel") if head else None},
+        "stepper": (S_name.get(head_kind) if not a.cpu_dry_run else head["stepper"] + " [dry run]") if head_kind else None,
+        "value_transport": head_kind,
+        "ranks_seen": head["ranks_seen"] if head else 0,
+        "launched_by": "bench.py self-launch" if os.environ.get("AMT_BENCH_SELF_LAUNCHED") else "external launcher",
+        "verified_vs_oracle": (None if not head or head["verified_first_sweep"] is None else
+                               bool(head["verified_first_sweep"] and head["verified_later_sweep_after_new_inputs"])),
+        "transports": transports,
+        "ladder": ladder,
+        "preflight": {"devices": ndev, "device_name": pre[0].get("device_name"), "peer_access": pre[0].get("peer_access"),
+                      "rccl": pre[0].get("rccl"), "dev_shm_free_MiB": pre[0].get("dev_shm_free_MiB"),
+                      "HSA_ENABLE_IPC_MODE_LEGACY": pre[0].get("HSA_ENABLE_IPC_MODE_LEGACY")},
+    }
+    if head:
+        ev_max = head["rank_event_ms_per_step_min_max"][1]
+        achieved = abytes / world / (ev_max * 1e-3) / 1e9                       # GB/s per GPU, slowest rank
+        out["rank_ms_per_step_min_max"] = head["rank_event_ms_per_step_min_max"]
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "algorithmic_bytes_per_launch": abytes // world, "kernel_ms_per_launch": round(ev_max, 4),
+                           "per_rank_achieved_GBps": head["per_rank_achieved_GBps"], "per_rank_frac": head["per_rank_frac_of_8TBps"],
+                           "aggregate_GBps": head["aggregate_GBps"], "aggregate_peak_GBps": HBM_PEAK_GBS * world,
+                           "frac_of_aggregate_peak": head["frac_of_aggregate_peak"],
+                           "note": "per rank: the algorithmic bytes of the rank's own rows / its HIP-event time per sweep (interior + exchange "
+                                   "+ boundary rows), against 8 TB/s; `achieved` / `frac` are the slowest rank's share of an even split"}
+    if a.cpu_dry_run:
+        gb_rows = [r["rows"][1] - r["rows"][0] + 1 for r in results[head_kind]] if head_kind else None
+        out.update(dry_run=True, note="CPU plumbing run of the N > 1 path with an injected compute callable: not a measurement")
+        out["config"]["rows_per_rank"] = gb_rows
+    elif ndev and world > ndev:
+        out["note"] = (f"{world} ranks share {ndev} device(s): a correctness run of the whole N > 1 path (slabs, halo exchange, "
+                       "verification, reductions); `value` is NOT a scaling measurement")
+    return out
+
+
 def main():
     a = parse()
+    if a.rung_child:
+        return rung_child(a)
     if a.emulate_world > 1:
         return emulate_one_rank(a)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         raise SystemExit(self_launch(a))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and a.stepper == "native" and a.backend == "nccl":
+        return supervise(a)             # the ladder of transports, every rung in fresh child processes
     if a.cpu_dry_run:
-        return dry_run_rank(a)
-    return run_rank(a)
+        raise SystemExit("bench.py --cpu-dry-run serves the N > 1 ladder only (--gpus N, native stepper)")
+    return run_rank(a)                  # N = 1, and the in-process bring-up modes (--backend gloo, --stepper torch)
 
 
 if __name__ == "__main__":

@@ -134,6 +134,21 @@ int amt_advance_mu_t_f64(
 int amt_host_pin(void *ptr, size_t bytes);
 int amt_host_unpin(void *ptr);
 
+/* One call, several devices.  The reference's host call IS its multi-GPU call: advance_mu_t_no_async.cu:108-162 splits j over
+ * its `GPUs` devices inside one advance_mu_t(...), refills every device's halo rows from the host arrays (:135-160), launches and
+ * gathers per device (:329-390).  amt_host_set_devices(n, ids) gives the calling host thread n DEVICE SLOTS (ids may name a device
+ * more than once); from then on each one-shot call of that thread cuts its tile's rows jts..jte into n contiguous pieces (uneven
+ * where they do not divide) and runs them at the same time, one per slot, each piece a tile of the same domain whose halo rows
+ * come from the HOST arrays exactly as the reference's do -- no traffic between the devices, same bits as the one-device call.
+ * The one-shot path is bound by the host link; a node has one link per device.  Every slot keeps its
+ * own workspace, residency cache and deferred outputs on its device; the control calls below (amt_host_cache_*, _invalidate,
+ * _defer, _fetch, _stale, _release) act on all slots.  n = 0 turns it off (what the slots' devices alone hold comes down first).
+ * AMT_ONESHOT_DEVICES="0,1,2,3" or "all" in the environment does the same for every thread that never calls this (the Fortran
+ * drop-in module is one CALL and has nowhere to put another).  amt_host_devices returns the number of slots of the calling thread
+ * and their device ids. */
+int amt_host_set_devices(int n, const int *device_ids);
+int amt_host_devices(int *device_ids, int cap);
+
 /* The one-shot calls keep their device workspace (three streams, six events, the buffer arena
  * when it is at most 1 GiB) per calling host thread between calls, instead of the reference
  * wrapper's allocate-and-free on every call (advance_mu_t_no_async.cu:178-244,392-423), which
@@ -489,6 +504,12 @@ int amt_march_set_xchunk(int n);
  * nothing).  0, 0 = the defaults (AMT_MARCH_BESIDE_ROUNDS / AMT_MARCH_BESIDE_RESERVE in the environment, else 2 and 0).
  * Measured: profiles/r05_slab_ab.md. */
 int amt_march_set_beside(int rounds, int reserve_cus);
+/* Cache policy of the three once-read streams t, ft, ww_1 (same bits either way): -1 (default) by the
+ * row length -- non-temporal loads (kernel amt_march_kernel) where rows are whole 128-byte lines, plain loads (kernel
+ * amt_march_kernel_cached) where they are not (WRF's own unpadded ims:ime: neighbouring tiles then share the edge line of those
+ * streams, and nt would drop it from L2: +3.5 % HBM reads, profiles/r06_rows4098_nt.md); 0 = always plain, 1 = always non-temporal.
+ * AMT_MARCH_NT in the environment sets the same at load time. */
+int amt_march_set_stream_policy(int policy);
 
 #ifdef __cplusplus
 }

@@ -56,3 +56,67 @@ def test_a_dying_rank_takes_the_eight_down():
     assert "rank 5 exited with code 7" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert time.time() - t0 < 100
+
+
+# ---- the first-contact ladder: every transport is a rung run in FRESH child processes under a timeout; the
+# ---- outcomes a real 8-GPU node can produce on first contact are injected here (bench.py: AMT_BENCH_TEST_RUNG_<NAME>)
+def _ladder(extra_env, *extra_args, gpus=3, expect_rc=0, timeout=300):
+    env = _env()
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, str(SHIM), "--gpus", str(gpus), "--cpu-dry-run", "--ni", "40", "--nk", "6", "--nj", "31",
+                        "--steps", "2", "--warmup", "2", "--launch-timeout", "200", *extra_args],
+                       capture_output=True, text=True, env=env, timeout=timeout, cwd=str(ROOT))
+    assert r.returncode == expect_rc, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), r.stderr
+
+
+def test_ladder_both_transports_are_timed_and_verified_on_new_inputs():
+    out, _ = _ladder({})
+    assert [x["rung"] for x in out["ladder"]] == ["preflight", "rccl", "ipc"] and all(x["ok"] for x in out["ladder"])
+    assert out["value_transport"] == "rccl" and out["value"] == out["transports"]["rccl"]["value"]
+    for t in ("rccl", "ipc"):
+        rec = out["transports"][t]
+        assert rec["ok"] and rec["verified_first_sweep"] is True and rec["verified_later_sweep_after_new_inputs"] is True
+        assert rec["value"] > 0 and len(rec["per_rank_achieved_GBps"]) == 3 and rec["ranks_seen"] == 3
+    assert out["verified_vs_oracle"] is True
+    assert out["roofline"]["aggregate_peak_GBps"] == 3 * 8000.0 and len(out["roofline"]["per_rank_frac"]) == 3
+
+
+def test_ladder_rccl_init_refuses_then_the_ipc_rung_carries_the_line():
+    """ncclCommInitRank returning an error on every rank (what RCCL does when it dislikes the node): the rung fails cleanly, the
+    IPC rung runs in fresh processes, `value` is its figure and the line says which transport it is and why."""
+    out, err = _ladder({"AMT_BENCH_TEST_RUNG_RCCL": "refuse"})
+    assert out["value_transport"] == "ipc" and out["value"] == out["transports"]["ipc"]["value"] and out["verified_vs_oracle"] is True
+    assert out["transports"]["rccl"]["ok"] is False and "ncclCommInitRank failed" in out["transports"]["rccl"]["errors"][0]
+    assert [x["ok"] for x in out["ladder"]] == [True, False, True]
+    assert "rung rccl failed" in err
+
+
+def test_ladder_a_rank_that_hangs_in_rccl_costs_the_rung_not_the_launch():
+    """One rank never comes back from its RCCL set-up (a peer that cannot be reached): its supervisor ends the child by pid after
+    --rung-timeout, the other ranks' children -- blocked waiting for it -- go the same way, and every rank goes on to the IPC rung."""
+    t0 = time.time()
+    out, _ = _ladder({"AMT_BENCH_TEST_RUNG_RCCL": "hang:1"}, "--rung-timeout", "25", "--comm-timeout", "30")   # (a healthy rung on a busy 8-core host needs ~5 s)
+    assert time.time() - t0 < 200
+    rccl = out["transports"]["rccl"]
+    assert rccl["ok"] is False and 1 in rccl["timed_out_ranks"]
+    assert out["value_transport"] == "ipc" and out["transports"]["ipc"]["ok"] and out["verified_vs_oracle"] is True
+
+
+def test_ladder_ipc_handle_refused_rccl_line_unaffected():
+    out, _ = _ladder({"AMT_BENCH_TEST_RUNG_IPC": "open_fails"})
+    assert out["value_transport"] == "rccl" and out["transports"]["rccl"]["ok"]
+    assert out["transports"]["ipc"]["ok"] is False and "hipIpcOpenMemHandle" in out["transports"]["ipc"]["errors"][0]
+
+
+def test_ladder_nothing_works_the_line_says_so_and_the_exit_code_is_not_zero():
+    out, _ = _ladder({"AMT_BENCH_TEST_RUNG_RCCL": "refuse", "AMT_BENCH_TEST_RUNG_IPC": "open_fails"}, expect_rc=5)
+    assert out["value"] is None and out["value_transport"] is None
+    assert [x["ok"] for x in out["ladder"]] == [True, False, False]
+
+
+def test_single_transport_request_runs_one_rung():
+    out, _ = _ladder({}, "--transport", "ipc", gpus=2)
+    assert [x["rung"] for x in out["ladder"]] == ["preflight", "ipc"] and out["value_transport"] == "ipc"

@@ -91,7 +91,9 @@ def test_forced_shape_matches_oracle(pkg, oracle, force, shape):
                 pkg.advance_mu_t(*dev.args(), variant=pkg.VARIANT_MARCH)
                 torch.cuda.synchronize()
                 name = L.amt_march_last_kernel().decode()
-                assert f", {vw}, {kpt}, {hl}, {xd}, FULL, {'true' if dma else 'false'}, {wm}>" in name, name
+                # (the label ends with the cache policy of the once-read streams: ", nt>" for rows that are whole 128-byte lines, else ", cached>")
+                assert f", {vw}, {kpt}, {hl}, {xd}, FULL, {'true' if dma else 'false'}, {wm}, " in name, name
+                assert (", nt>" if (b.idim * np.dtype(dtype).itemsize) % 128 == 0 else ", cached>") in name, name
                 got = dev.to_host()
                 for f in S.OUTPUTS:
                     assert bits_equal(got.arrays[f], want.arrays[f]), f"{_id(shape)} nk={nk} aligned={aligned} jrows={jrows}: {f} ({name})"

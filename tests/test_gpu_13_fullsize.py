@@ -181,7 +181,7 @@ def test_a_block_at_the_offset_limit(pkg, oracle, dtype, ni, nk, dma):
         label = L.amt_march_last_kernel().decode()
     finally:
         L.amt_march_force_shape(0, 0, 0, -1, 1, 0, 0)
-    assert ("true, 16>" in label or "true, 12>" in label) == bool(dma), label
+    assert ("true, 16, " in label or "true, 12, " in label) == bool(dma), label
     jrows = int(re.search(r"jrows=(\d+)", label).group(1))
     assert jrows == limit, (label, limit)
     assert (jrows + 2) * row_bytes <= 2**32 < (jrows + 6) * row_bytes + 40 * b.idim * wbytes, "the block should end at the mark"

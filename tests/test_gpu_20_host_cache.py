@@ -355,6 +355,45 @@ def test_deferred_outputs_survive_a_change_of_device(pkg, oracle):
         pkg.host_release()
 
 
+def test_deferred_outputs_survive_a_change_of_device_one_gpu_twin(pkg, oracle):
+    """The same property without a second device: AMT_TEST_PRETEND_DEVICE_CHANGE=2 makes the SECOND one-shot
+    call of a thread give the workspace up exactly as HostWorkspace::prepare() does when the thread's device has changed (streams,
+    arena and every kept copy dropped).  A fresh thread, so that the call count is known: sub-step 1 leaves its outputs on the
+    device only; sub-step 2 -- "on the other device" -- must find sub-step 1's results in the HOST arrays, i.e. they came down
+    before the drop.  Were they lost, sub-step 2 would start from the arrays as made and the result would be one sweep, not two."""
+    import os
+    import threading
+    box = {}
+
+    def body():
+        try:
+            b = pkg.synth.domain_bounds(64, 10, 12)
+            pkg.host_defer(None, True)
+            a = pkg.synth.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=1)
+            want = a.copy()
+            oracle.advance_mu_t(*want.args())
+            pkg.advance_mu_t(*a.args())                              # call 1 of this thread: outputs stay on the device
+            assert pkg.host_stale(None)
+            os.environ["AMT_TEST_PRETEND_DEVICE_CHANGE"] = "2"
+            pkg.advance_mu_t(*a.args())                              # call 2: the workspace of the "old device" is given up first
+            os.environ.pop("AMT_TEST_PRETEND_DEVICE_CHANGE")
+            oracle.advance_mu_t(*want.args())
+            pkg.host_fetch(None)
+            assert_patch_equal(pkg, a, want, "two sub-steps around a (pretended) change of device")
+        except BaseException as e:  # noqa: BLE001
+            box["error"] = e
+        finally:
+            os.environ.pop("AMT_TEST_PRETEND_DEVICE_CHANGE", None)
+            pkg.host_defer(None, False)
+            pkg.host_release()
+
+    th = threading.Thread(target=body)
+    th.start()
+    th.join()
+    if "error" in box:
+        raise box["error"]
+
+
 def test_a_call_that_fails_part_way_poisons_the_deferred_copies(pkg, oracle, monkeypatch):
     """t, mu and level 1 of ww are advanced in place on the device; a call that fails after its kernels went out
     leaves them partly a sub-step ahead.  No retry may run on them and no fetch may bring them down until the caller says the

@@ -1,0 +1,144 @@
+"""One call, several devices: amt_host_set_devices / AMT_ONESHOT_DEVICES.  The reference's host call IS
+its multi-GPU call -- advance_mu_t_no_async.cu:108-162 splits j over its devices inside one advance_mu_t(...), refills every
+device's halo rows from the host arrays (:135-160; re-uploads :245-306; gathers :366-390).  Here the calling thread's one-shot
+calls fan their rows over device SLOTS, each slot a worker thread with its own workspace, residency cache and deferred outputs
+on its device.  The box has one GPU: the slot list names device 0 three times (three concurrent pieces on one device) -- what
+is tested is the split, the host-sourced halos, the per-slot state and the forwarding of the control calls; bits are the
+oracle's (the one-device call's)."""
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+from test_gpu_10_parity import assert_patch_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+FLAGS = [dict(), dict(specified=True), dict(specified=True, periodic_x=True), dict(nested=True)]
+
+
+@pytest.fixture()
+def slots(pkg):
+    pkg.host_set_devices([0, 0, 0])
+    assert pkg.host_devices() == [0, 0, 0]
+    yield pkg
+    pkg.host_cache_enable(False, check=False)
+    pkg.host_defer(None, False)
+    pkg.host_set_devices(())
+    assert pkg.host_devices() == []
+    pkg.host_release()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("flags", FLAGS, ids=["none", "specified", "specified+periodic_x", "nested"])
+def test_three_slots_uneven_rows_every_flag_set(slots, oracle, dtype, flags):
+    """31 rows over three slots (10, 10, 11); `specified` / `nested` clip the outermost rows of the first and last piece exactly as
+    they clip the unsplit tile (module_small_step_em.f90:103-106).  Every array of the call is compared: inputs untouched, outputs
+    outside the window untouched."""
+    pkg = slots
+    b = pkg.synth.domain_bounds(150, 24, 31)
+    got = pkg.synth.make_patch(b, pkg.GridConfig(**flags), dtype=dtype, seed=71)
+    want = got.copy()
+    for _ in range(2):
+        pkg.advance_mu_t(*got.args())
+        oracle.advance_mu_t(*want.args())
+    assert_patch_equal(pkg, got, want, f"three slots, {flags}")
+    assert "amt_march_kernel" in pkg.load_library().amt_march_last_kernel().decode() or "amt_column" in pkg.load_library().amt_march_last_kernel().decode()
+
+
+def test_a_tile_of_a_larger_domain_and_more_slots_than_rows(slots, oracle):
+    """The call's tile is rows 5..6 of a 20-row domain (an OpenMP tile): two rows over three slots -- one slot has nothing to
+    do -- and unpadded memory."""
+    pkg = slots
+    g = pkg.synth.domain_bounds(97, 12, 20)
+    b = g.replace(jts=5, jte=6, its=3, ite=90)
+    got = pkg.synth.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=5)
+    want = got.copy()
+    pkg.advance_mu_t(*got.args())
+    oracle.advance_mu_t(*want.args())
+    assert_patch_equal(pkg, got, want, "two rows over three slots")
+
+
+def test_sub_step_loop_with_cache_and_deferred_outputs_per_slot(slots, oracle, monkeypatch):
+    """The acoustic loop at the reference's boundary on three slots: constants resident per slot (checksum debug mode on), outputs
+    deferred per slot; u, v rewritten on the host before every sub-step (advance_uv); nothing of the outputs reaches the host
+    until the fetch, which gathers every slot's rows.  Several chunks per slot (AMT_STREAM_ROWS)."""
+    pkg = slots
+    monkeypatch.setenv("AMT_STREAM_ROWS", "4")
+    pkg.host_cache_enable(True, check=True)
+    pkg.host_defer(None, True)
+    b = pkg.synth.domain_bounds(130, 20, 37)
+    got = pkg.synth.make_patch(b, pkg.GridConfig(specified=True), dtype=np.float64, seed=23)
+    want = got.copy()
+    before = got.copy()
+    rng = np.random.default_rng(9)
+    for step in range(4):
+        if step:
+            for n in ("u", "v"):
+                d = (rng.standard_normal(got.arrays[n].shape) * 1e-3)
+                got.arrays[n] += d
+                want.arrays[n] += d
+        pkg.advance_mu_t(*got.args())
+        oracle.advance_mu_t(*want.args())
+    assert pkg.host_stale(None)
+    win = (slice(2 - b.jms, b.jde - 1 - b.jms), slice(None), slice(2 - b.ims, b.ide - 1 - b.ims))   # specified: rows / columns 2..n-1
+    assert not bits_equal(got.arrays["t"][win], want.arrays["t"][win]), "deferred: the host array must not have been updated yet"
+    assert np.isnan(got.arrays["t"][win][:, :-1]).all(), "check mode: the window of a deferred host array holds NaN canaries"
+    pkg.host_fetch(None)
+    assert not pkg.host_stale(None)
+    assert_patch_equal(pkg, got, want, "four sub-steps on three slots, cache + deferred outputs")
+    del before
+
+
+def test_turning_the_slots_off_brings_down_what_they_hold(pkg, oracle):
+    pkg.host_set_devices([0, 0])
+    try:
+        pkg.host_defer(None, True)
+        b = pkg.synth.domain_bounds(64, 10, 12)
+        got = pkg.synth.make_patch(b, pkg.GridConfig(), dtype=np.float64, seed=2)
+        want = got.copy()
+        pkg.advance_mu_t(*got.args())
+        oracle.advance_mu_t(*want.args())
+        pkg.host_set_devices(())                                     # what only the slots' devices hold comes down first
+        assert_patch_equal(pkg, got, want, "after amt_host_set_devices(0)")
+        pkg.advance_mu_t(*got.args())                                # the plain one-device path again, still deferred
+        oracle.advance_mu_t(*want.args())
+        pkg.host_fetch(None)
+        assert_patch_equal(pkg, got, want, "one device after the slots were turned off")
+    finally:
+        pkg.host_defer(None, False)
+        pkg.host_set_devices(())
+        pkg.host_release()
+
+
+def test_bad_device_lists_are_refused(pkg):
+    from wrf_model_cuda_sample_amd import lib
+    with pytest.raises(lib.AmtError) as e:
+        pkg.host_set_devices([0, 99])
+    assert e.value.status == lib.ERR_INVALID_ARG and "device 99" in str(e.value)
+    assert pkg.host_devices() == []
+
+
+@pytest.mark.parametrize("real", ["f64", "f32"])
+def test_fortran_drop_in_with_AMT_ONESHOT_DEVICES(pkg, oracle, tmp_path, real):
+    """The Fortran host cannot add a call (the drop-in module IS the one CALL advance_mu_t): AMT_ONESHOT_DEVICES=0,0,0 in the
+    environment gives its thread three slots.  Same dump as the one-device run of tests/test_gpu_21: the oracle's bits."""
+    import cases
+    exe = ROOT / "wrf-model-cuda-sample_amd" / "fortran" / f"advance_mu_t_driver_{real}"
+    if not exe.exists():
+        pytest.skip("Fortran driver not built (no Fortran compiler)")
+    dtype = np.float64 if real == "f64" else np.float32
+    r = subprocess.run([str(exe), "64", "40", "64", "3", str(tmp_path), "1"], capture_output=True, text=True,
+                       env=dict(os.environ, AMT_ONESHOT_DEVICES="0,0,0"), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fans its rows over 3 device slot(s): 0 0 0" in r.stdout, r.stdout
+    assert "differing elements = 0" in r.stdout
+    want = cases.make_case(pkg, "64x40x64", "specified", dtype)
+    for _ in range(3):
+        oracle.advance_mu_t(*want.args())
+    for n in pkg.synth.OUTPUTS:
+        got = np.fromfile(tmp_path / f"{n}.bin", dtype=dtype).reshape(want.arrays[n].shape)
+        assert bits_equal(got, want.arrays[n]), n

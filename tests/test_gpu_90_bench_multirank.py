@@ -1,8 +1,10 @@
 """bench.py N > 1 as the driver invokes it: `python bench.py --gpus N` with no launcher (the script
-starts its own rank processes) and under torch.distributed.run.  On the one-GPU box the ranks share
-the device through the gloo bring-up transport (RCCL refuses two ranks on one device); the RCCL
-paths (native amt_slab_* stepper and the torch P2P one) need two visible GPUs and are skipped, not
-removed, without them."""
+starts its own rank processes) and under torch.distributed.run.  The default path is the first-contact ladder
+(bench.py: supervise): per rank a supervisor that never touches the GPU, every transport a rung in fresh child
+processes.  On the one-GPU box the ranks share the device: the IPC rung really runs (two to eight processes), the
+RCCL rung is refused by RCCL (two ranks on one device) and must say so; the in-process bring-up modes
+(--backend gloo, --stepper torch) stay.  The RCCL paths with real ranks need two visible GPUs and are
+skipped, not removed, without them."""
 import json
 import os
 import subprocess
@@ -112,7 +114,9 @@ def test_native_stepper_with_two_real_ranks():
     out = _run(["--gpus", "2"] + SMALL)
     assert out["stepper"].startswith("native") and out["ranks_seen"] == 2
     assert out["verified_vs_oracle"] is True
-    assert out["config"]["halo_transport"] == "rccl"
+    assert out["config"]["halo_transport"] == "rccl" and out["value_transport"] == "rccl"
+    assert out["transports"]["rccl"]["ok"] and out["transports"]["ipc"]["ok"]         # both transports timed on real devices
+    assert out["transports"]["ipc"]["halo_pull"] == "copy engine"
 
 
 def test_torch_stepper_with_two_real_ranks():
@@ -159,6 +163,14 @@ def test_single_gpu_line_carries_the_contract_keys():
     # the HBM traffic of a launch is re-measured in the run (two rocprofv3 --pmc child passes), or the line says why not
     assert rf.get("traffic_same_run_error") or (rf["traffic"] and 0.9 < rf["traffic_over_algorithmic"] < 1.5
                                                 and rf["traffic_source"].startswith("measured in this run"))
+    # the layout of the timed state is in the record, and WRF's own unpadded rows are timed beside it in the same run
+    cfg = out["config"]
+    assert cfg["aligned"] is True and cfg["row_bytes_mod_128"] == 0 and cfg["idim"] == 320 and cfg["ims"] == -31   # 256 columns: -31..288
+    w = out["wrf_rows"]
+    assert "error" not in w, w
+    assert w["idim"] == 258 and w["row_bytes_mod_128"] == (258 * 8) % 128 and w["ms_per_step"] > 0 and 0 < w["frac"] < 1
+    assert rf.get("traffic_same_run_error") or 0.9 < w["traffic_over_algorithmic"] < 1.6
+    assert cb["build_overlapped_with_the_gpu_part"] is True
     assert out["config"]["placement_probe_ms"] is None or len(out["config"]["placement_probe_ms"]) >= 2
     if out["config"]["placement_probe_ms"]:
         pl = out["placement"]
@@ -166,20 +178,42 @@ def test_single_gpu_line_carries_the_contract_keys():
         assert 0 < pl["frac_placement_median"] <= rf["frac"] + 1e-6
 
 
-def test_two_ranks_on_one_device_over_rccl_end_with_a_diagnosis_not_a_hang():
-    """The first contact with RCCL happens on the driver's clock: whatever goes wrong there must end every
-    rank, non-zero, with what it knows, well inside --comm-timeout.  Two ranks on ONE device is the failure this
-    box can produce: ncclCommInitRank refuses (or blocks) and so does torch.distributed's own group."""
+def test_first_contact_ladder_on_one_device_rccl_refuses_ipc_carries_the_line():
+    """`bench.py --gpus 2 --share-gpu` with the default --transport both -- the command an 8-GPU node would get, on the one-GPU
+    box: every transport is a rung run in FRESH child processes under a timeout.  RCCL refuses two ranks on one device (the
+    failure this box can produce: the rung fails cleanly on both ranks and says why), the IPC rung then runs, is verified on
+    its first sweep AND on a later sweep with new inputs and re-poisoned halos, and carries `value`; the line names the
+    transport of `value`, both rungs' outcomes and the preflight's view of the node."""
     import time
     if _gpus() >= 2:
         pytest.skip("two devices visible: the real two-rank tests run instead")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     t0 = time.time()
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-gpu", "--comm-timeout", "40",
-                        "--launch-timeout", "300", "--no-box-probe", "--probe-placements", "1"] + SMALL,
+    out = _run(["--gpus", "2", "--share-gpu", "--comm-timeout", "40", "--rung-timeout", "150", "--launch-timeout", "500",
+                "--no-box-probe", "--probe-placements", "1"] + SMALL, timeout=600)
+    assert [x["rung"] for x in out["ladder"]][:3] == ["preflight", "rccl", "ipc"]
+    assert out["ladder"][1]["ok"] is False and out["transports"]["rccl"]["ok"] is False
+    assert any("ncclCommInitRank" in e or "RCCL" in e or "rccl" in e for e in out["transports"]["rccl"]["errors"]), out["transports"]["rccl"]
+    ipc = out["transports"]["ipc"]
+    assert ipc["ok"] and ipc["verified_first_sweep"] is True and ipc["verified_later_sweep_after_new_inputs"] is True
+    assert out["value_transport"] == "ipc" and out["value"] == ipc["value"] and out["verified_vs_oracle"] is True
+    assert out["preflight"]["devices"] == 1 and out["preflight"]["rccl"]["loadable"] is True
+    assert len(out["roofline"]["per_rank_frac"]) == 2 and out["roofline"]["aggregate_peak_GBps"] == 16000.0
+    assert "NOT a scaling measurement" in out["note"]
+    assert time.time() - t0 < 400
+
+
+def test_first_contact_ladder_rccl_only_falls_back_to_torch_and_then_reports_failure():
+    """--transport rccl on one shared device: the native rung is refused, the torch.distributed fallback rung is refused as well
+    (RCCL again): the launch ends non-zero with a line that says so (value null, every rung's error), not with a hang."""
+    if _gpus() >= 2:
+        pytest.skip("two devices visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-gpu", "--transport", "rccl", "--comm-timeout", "40",
+                        "--rung-timeout", "120", "--launch-timeout", "400", "--no-box-probe", "--probe-placements", "1"] + SMALL,
                        capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
-    took = time.time() - t0
     assert r.returncode != 0, r.stdout[-1000:]
-    assert "FATAL" in r.stderr and "[rank " in r.stderr, r.stderr[-3000:]
-    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no measurement line may come out of a failed launch"
-    assert took < 280, took
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] is None and [x["rung"] for x in out["ladder"]] == ["preflight", "rccl", "torch-rccl"]
+    assert not any(x["ok"] for x in out["ladder"][1:])

@@ -21,6 +21,7 @@ from .config import GridConfig  # noqa: F401
 from .lib import AmtError, load_library, library_path  # noqa: F401
 from .api import advance_mu_t, bind_device_call, compute_window, VARIANT_AUTO, VARIANT_COLUMN, VARIANT_MARCH, LAUNCH_BESIDE_OTHERS  # noqa: F401
 from .api import host_cache_enable, host_invalidate, host_defer, host_fetch, host_stale, host_release, held_arrays  # noqa: F401
+from .api import host_set_devices, host_devices  # noqa: F401
 from . import synth  # noqa: F401
 from . import patch  # noqa: F401
 from . import wrfdump  # noqa: F401

@@ -218,6 +218,22 @@ def host_release() -> None:
     _forget_if_idle()
 
 
+def host_set_devices(device_ids=()) -> None:
+    """One call, several devices (amt_host_set_devices; the reference's own host call splits j over its GPUs,
+    advance_mu_t_no_async.cu:108-162): from now on every one-shot call of this thread fans its tile's rows over these device
+    slots -- ids may repeat -- with halo rows from the host arrays; () turns it off."""
+    ids = [int(d) for d in device_ids]
+    arr = (ctypes.c_int * max(len(ids), 1))(*ids)
+    _lib.check(_lib.load_library().amt_host_set_devices(len(ids), arr))
+
+
+def host_devices():
+    """The device slots of the calling thread ([] when its one-shot calls run on the current device only)."""
+    arr = (ctypes.c_int * 64)()
+    n = int(_lib.load_library().amt_host_devices(arr, 64))
+    return [int(arr[k]) for k in range(n)]
+
+
 def host_stale(array=None) -> bool:
     """Is the device copy of a deferred output (None: of any) newer than the host array?  Raises AmtError when the device
     copy is undefined because a call failed part-way (``host_invalidate`` makes the host array the truth again)."""

@@ -180,25 +180,23 @@ __device__ __forceinline__ AmtVec<T, VW> amt_ldv(const T *ubase, unsigned voff)
     typedef typename AmtRaw<T, VW>::type R;
     return amt_unraw<T, VW>(*reinterpret_cast<const R *>(reinterpret_cast<const char *>(ubase) + voff));
 }
-// once-read inputs (level = which AMT_NT_LOAD setting turns the nt policy on for this stream)
-template <int LEVEL, typename T, int VW>
+// once-read inputs (LEVEL = which setting of the kernel's NTL turns the nt policy on for this stream)
+template <int LEVEL, int NTL, typename T, int VW>
 __device__ __forceinline__ AmtVec<T, VW> amt_ldv_stream(const T *ubase, unsigned voff)
 {
     typedef typename AmtRaw<T, VW>::type R;
-#if AMT_NT_LOAD
-    if (AMT_NT_LOAD >= LEVEL)
+    if constexpr (NTL >= LEVEL)
         return amt_unraw<T, VW>(__builtin_nontemporal_load(reinterpret_cast<const R *>(reinterpret_cast<const char *>(ubase) + voff)));
-#endif
-    return amt_unraw<T, VW>(*reinterpret_cast<const R *>(reinterpret_cast<const char *>(ubase) + voff));
+    else
+        return amt_unraw<T, VW>(*reinterpret_cast<const R *>(reinterpret_cast<const char *>(ubase) + voff));
 }
-template <int LEVEL, typename T>
+template <int LEVEL, int NTL, typename T>
 __device__ __forceinline__ T amt_ld_stream(const T *ubase, unsigned voff)
 {
-#if AMT_NT_LOAD
-    if (AMT_NT_LOAD >= LEVEL)
+    if constexpr (NTL >= LEVEL)
         return __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(ubase) + voff));
-#endif
-    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(ubase) + voff);
+    else
+        return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(ubase) + voff);
 }
 // store of a lane's VW columns: one wide store when all of them are window columns (every lane
 // but the one or two the window edge cuts), element stores otherwise
@@ -304,7 +302,19 @@ template <typename T, int VW, int KPT, int HL, int XD, bool DMA, int WM> constex
     return 1;
 }
 
-template <typename T, int VW, int KPT, int HL, int XD, bool FULL, bool DMA, int WM>
+// NTL: the cache policy of the once-read streams (0: none; 1: t, ft, ww_1 non-temporal; 2: u, u_1 too).  Same bits, same
+// everything else; the launcher instantiates and picks between two:
+//   NTL = AMT_NT_LOAD (1)   rows that are whole 128-byte lines: no line of those streams is ever wanted by a second workgroup, and
+//                           nt keeps them from evicting the lines that are (-1.4 % of a sweep, -0.8 % traffic on the padded
+//                           4096 x 60 x 4096 fp64 state).
+//   NTL = 0                 rows that are NOT whole lines (WRF's own ims:ime = 0:NI+1: 4098 x 8 B = 256 lines + 16 B): seven of
+//                           eight level rows of a tile end inside a line whose rest is the NEIGHBOUR tile's first columns of the
+//                           same streams, and nt asks L2 to drop exactly that line -- HBM reads 70.7 -> 67.7 GB per sweep (1.065
+//                           -> 1.031 x the algorithmic bytes; profiles/r06_rows4098_nt.md).
+// The launcher picks by (idim * sizeof(T)) % 128 (amt_march_set_stream_policy / AMT_MARCH_NT override it).  (A shared __device__
+// body under two __global__ names was tried first: it is not register-neutral -- the <float,2,6,.,12> shapes went from 164 VGPRs
+// and no scratch to 167 and 12 B/lane -- a template parameter of the kernel itself is.)
+template <typename T, int VW, int KPT, int HL, int XD, bool FULL, bool DMA, int WM, int NTL>
 __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p, const AmtMarchGrid g)
 {
     extern __shared__ __align__(16) unsigned char amt_smem[];
@@ -685,8 +695,8 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                 if (q < m0 || q >= m1) continue;
                 const unsigned oq = orow + lo(q);
                 if (XD < 1) g_v1[q] = amt_ldv<T, VW>(v1_b + js, oq);
-                if (XD < 2) { g_uu[q] = amt_ldv_stream<2, T, VW>(u_b, oq); g_un[q] = amt_ld_stream<2>(u_b + VW, oq); }
-                if (XD < 3) { g_u1[q] = amt_ldv_stream<2, T, VW>(u1_b, oq); g_u1n[q] = amt_ld_stream<2>(u1_b + VW, oq); }
+                if (XD < 2) { g_uu[q] = amt_ldv_stream<2, NTL, T, VW>(u_b, oq); g_un[q] = amt_ld_stream<2, NTL>(u_b + VW, oq); }
+                if (XD < 3) { g_u1[q] = amt_ldv_stream<2, NTL, T, VW>(u1_b, oq); g_u1n[q] = amt_ld_stream<2, NTL>(u1_b + VW, oq); }
             }
         };
 
@@ -770,13 +780,13 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
                         const T in = U[(kfw + m) * TC + lc + VW];
                         un = (il == TI - 1) ? UH[kfw + m + lh] : in;
                     } else if (PB > 1) { uu = g_uu[m]; un = g_un[m]; }
-                    else { uu = amt_ldv_stream<2, T, VW>(u_b, om); un = amt_ld_stream<2>(u_b + VW, om); }
+                    else { uu = amt_ldv_stream<2, NTL, T, VW>(u_b, om); un = amt_ld_stream<2, NTL>(u_b + VW, om); }
                     if (XD >= 3) {
                         u1 = amt_ldsv<T, VW>(U1 + (kfw + m) * TC + lc);
                         const T in = U1[(kfw + m) * TC + lc + VW];
                         u1n = (il == TI - 1) ? UH[nkr + kfw + m + lh] : in;
                     } else if (PB > 1) { u1 = g_u1[m]; u1n = g_u1n[m]; }
-                    else { u1 = amt_ldv_stream<2, T, VW>(u1_b, om); u1n = amt_ld_stream<2>(u1_b + VW, om); }
+                    else { u1 = amt_ldv_stream<2, NTL, T, VW>(u1_b, om); u1n = amt_ld_stream<2, NTL>(u1_b + VW, om); }
                     const V t1c = amt_ldsv<T, VW>(T1c + (kfw + m) * TC + lc);
                     const T tl_in = (T1c + (kfw + m) * TC + lc)[-1], tr_in = T1c[(kfw + m) * TC + lc + VW];
                     const T tl = (il == 0) ? THc[(kfw + m) * 2 + 2 * lh] : tl_in;
@@ -827,9 +837,9 @@ __global__ __launch_bounds__(WM * 64) void amt_march_kernel(const AmtParams<T> p
 #pragma unroll
                 for (int m = 0; m < KPT; ++m) {
                     const unsigned om = o3 + lo(m);
-                    told[m] = amt_ldv_stream<1, T, VW>(t_b, om);
-                    ftk[m] = amt_ldv_stream<1, T, VW>(ft_b, om);
-                    w1[m] = amt_ldv_stream<1, T, VW>(ww1_b, om);
+                    told[m] = amt_ldv_stream<1, NTL, T, VW>(t_b, om);
+                    ftk[m] = amt_ldv_stream<1, NTL, T, VW>(ft_b, om);
+                    w1[m] = amt_ldv_stream<1, NTL, T, VW>(ww1_b, om);
                 }
             }
             AMT_STAMP(stamp_slot, 3);
@@ -1003,16 +1013,16 @@ static bool amt_march_shape_feasible(int wbytes, const AmtMarchShape &s, int nk)
 
 template <typename T> struct AmtMarchEntry {
     AmtMarchShape shape;
-    const void *kernel[2];                                         // [FULL]
-    unsigned lds_granted[2];                                       // bit d: device d was told this kernel may use all of LDS
-    void (*launch[2])(hipStream_t, const AmtParams<T> &, const AmtMarchGrid &, int nw, size_t lds);
-    const char *name;
+    const void *kernel[4];                                         // [2 * cached + FULL]
+    unsigned lds_granted[4];                                       // bit d: device d was told this kernel may use all of LDS
+    void (*launch[4])(hipStream_t, const AmtParams<T> &, const AmtMarchGrid &, int nw, size_t lds);
+    const char *name, *name_cached;
 };
 
-template <typename T, int VW, int KPT, int HL, int XD, bool FULL, bool DMA, int WM>
+template <typename T, int VW, int KPT, int HL, int XD, bool FULL, bool DMA, int WM, int NTL>
 static void amt_march_launch_one(hipStream_t stream, const AmtParams<T> &p, const AmtMarchGrid &g, int nw, size_t lds)
 {
-    hipLaunchKernelGGL((amt_march_kernel<T, VW, KPT, HL, XD, FULL, DMA, WM>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
+    hipLaunchKernelGGL((amt_march_kernel<T, VW, KPT, HL, XD, FULL, DMA, WM, NTL>), dim3(g.nwg), dim3(nw * 64), lds, stream, p, g);
 }
 
 template <typename T> static AmtMarchEntry<T> *amt_march_table(int *n);
@@ -1020,10 +1030,14 @@ template <typename T> static AmtMarchEntry<T> *amt_march_table(int *n);
 #define AMT_ENTRY_IF(TT, VW, KPT, HL, XD, DMA, WM)                                                          \
     if constexpr (std::is_same<T, TT>::value)                                                               \
         tab[cnt++] = AmtMarchEntry<T>{AmtMarchShape{VW, KPT, HL, XD, DMA, WM},                                \
-            {reinterpret_cast<const void *>(amt_march_kernel<TT, VW, KPT, HL, XD, false, DMA, WM>),           \
-             reinterpret_cast<const void *>(amt_march_kernel<TT, VW, KPT, HL, XD, true, DMA, WM>)}, {0u, 0u}, \
-            {amt_march_launch_one<TT, VW, KPT, HL, XD, false, DMA, WM>, amt_march_launch_one<TT, VW, KPT, HL, XD, true, DMA, WM>}, \
-            "amt_march_kernel<" #TT ", " #VW ", " #KPT ", " #HL ", " #XD ", FULL, " #DMA ", " #WM ">"};
+            {reinterpret_cast<const void *>(amt_march_kernel<TT, VW, KPT, HL, XD, false, DMA, WM, AMT_NT_LOAD>),     \
+             reinterpret_cast<const void *>(amt_march_kernel<TT, VW, KPT, HL, XD, true, DMA, WM, AMT_NT_LOAD>),      \
+             reinterpret_cast<const void *>(amt_march_kernel<TT, VW, KPT, HL, XD, false, DMA, WM, 0>),               \
+             reinterpret_cast<const void *>(amt_march_kernel<TT, VW, KPT, HL, XD, true, DMA, WM, 0>)}, {0u, 0u, 0u, 0u}, \
+            {amt_march_launch_one<TT, VW, KPT, HL, XD, false, DMA, WM, AMT_NT_LOAD>, amt_march_launch_one<TT, VW, KPT, HL, XD, true, DMA, WM, AMT_NT_LOAD>, \
+             amt_march_launch_one<TT, VW, KPT, HL, XD, false, DMA, WM, 0>, amt_march_launch_one<TT, VW, KPT, HL, XD, true, DMA, WM, 0>}, \
+            "amt_march_kernel<" #TT ", " #VW ", " #KPT ", " #HL ", " #XD ", FULL, " #DMA ", " #WM ", nt>",    \
+            "amt_march_kernel<" #TT ", " #VW ", " #KPT ", " #HL ", " #XD ", FULL, " #DMA ", " #WM ", cached>"};
 
 template <typename T> static AmtMarchEntry<T> *amt_march_table(int *n)
 {
@@ -1055,8 +1069,9 @@ struct AmtMarchEnv {
     int dma, kpt, hl, vw, xd, jrows, verbose, wm, xchunk;
     int beside_rounds;     // least rounds of workgroups of a launch beside another stream's kernels (AmtParams::edges == 2)
     int beside_reserve;    // compute units such a launch is planned to leave free in every round
+    int nt;                // once-read streams: -1 by the row length (non-temporal where rows are whole 128-byte lines), 0 cached, 1 non-temporal
 };
-static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 0, 2, 0};
+static AmtMarchEnv g_march_env = {1, 0, 0, 0, -1, 0, 0, 0, 0, 2, 0, -1};
 // The instantiation the last plan of the calling thread chose (diagnosis / tests): "" before any launch.
 static thread_local char g_march_last[360] = "";
 extern "C" const char *amt_march_last_kernel(void) { return g_march_last; }
@@ -1071,7 +1086,7 @@ static const AmtMarchEnv &amt_march_env()
                        amt_env_int("AMT_MARCH_XD", -1), amt_env_int("AMT_MARCH_JROWS", 0),
                        amt_env_int("AMT_MARCH_VERBOSE", 0), amt_env_int("AMT_MARCH_WM", 0),
                        amt_env_int("AMT_MARCH_XCHUNK", 0), amt_env_int("AMT_MARCH_BESIDE_ROUNDS", 2),
-                       amt_env_int("AMT_MARCH_BESIDE_RESERVE", 0)};
+                       amt_env_int("AMT_MARCH_BESIDE_RESERVE", 0), amt_env_int("AMT_MARCH_NT", -1)};
         if (g_march_env.beside_rounds < 1) g_march_env.beside_rounds = 1;
         if (g_march_env.beside_reserve < 0) g_march_env.beside_reserve = 0;
     });
@@ -1088,6 +1103,14 @@ extern "C" int amt_march_force_shape(int vw, int kpt, int hl, int xd, int dma, i
     g_march_env.dma = dma != 0;
     g_march_env.jrows = jrows > 0 ? jrows : 0;
     g_march_env.wm = wm > 0 ? wm : 0;
+    ++g_march_generation;
+    return 0;
+}
+
+extern "C" int amt_march_set_stream_policy(int policy)
+{
+    (void)amt_march_env();
+    g_march_env.nt = policy < 0 ? -1 : policy ? 1 : 0;
     ++g_march_generation;
     return 0;
 }
@@ -1287,6 +1310,7 @@ template <typename T> struct AmtMarchPlan {
     bool ok;
     AmtMarchEntry<T> *entry;
     int full, nw;
+    int which;             // 2 * cached + full: index of the kernel in the entry
     size_t lds;
     AmtMarchGrid grid;
     char label[360];       // instantiation, rows per workgroup, schedule: what amt_march_last_kernel reports
@@ -1319,6 +1343,9 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
     pl.entry = amt_march_find<T>(s);
     const int lw = s.kpt * s.hl, tc = (64 / s.hl) * s.vw;
     pl.full = (p.nk % lw == 0 && amt_march_full_build_ok((int)sizeof(T), s)) ? 1 : 0;
+    // rows that are not whole 128-byte lines share their edge lines between neighbouring tiles: no nt policy there
+    const bool cached = env.nt < 0 ? ((size_t)p.idim * sizeof(T)) % 128 != 0 : env.nt == 0;
+    pl.which = (cached ? 2 : 0) + pl.full;
     pl.nw = amt_march_waves(s, p.nk);
     pl.lds = amt_march_lds_bytes((int)sizeof(T), s, p.nk);
     AmtMarchGrid &g = pl.grid;
@@ -1345,16 +1372,16 @@ template <typename T> static bool amt_march_make_plan(const AmtParams<T> &p, Amt
         // several host threads at once
         static std::mutex grant;
         std::lock_guard<std::mutex> lk(grant);
-        if (!(pl.entry->lds_granted[pl.full] >> (pl.dev & 31) & 1u)) {
-            hipError_t e = hipFuncSetAttribute(pl.entry->kernel[pl.full], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (!(pl.entry->lds_granted[pl.which] >> (pl.dev & 31) & 1u)) {
+            hipError_t e = hipFuncSetAttribute(pl.entry->kernel[pl.which], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-            pl.entry->lds_granted[pl.full] |= 1u << (pl.dev & 31);
+            pl.entry->lds_granted[pl.which] |= 1u << (pl.dev & 31);
         }
     }
     if (env.verbose)
         fprintf(stderr, "[amt march] nk %d idim %d window i %d..%d, %d rows -> %s %s: %d waves, %zu B LDS, %d tiles x %d blocks of %d rows\n",
-                p.nk, p.idim, p.i0, p.i1, nj, pl.entry->name, pl.full ? "FULL" : "ragged", pl.nw, pl.lds, g.ntile_i, g.njblk, g.jrows);
-    snprintf(pl.label, sizeof pl.label, "%s %s jrows=%d", pl.entry->name, pl.full ? "FULL" : "ragged", g.jrows);
+                p.nk, p.idim, p.i0, p.i1, nj, cached ? pl.entry->name_cached : pl.entry->name, pl.full ? "FULL" : "ragged", pl.nw, pl.lds, g.ntile_i, g.njblk, g.jrows);
+    snprintf(pl.label, sizeof pl.label, "%s %s jrows=%d", cached ? pl.entry->name_cached : pl.entry->name, pl.full ? "FULL" : "ragged", g.jrows);
     snprintf(g_march_last, sizeof g_march_last, "%s", pl.label);
     pl.ok = true;
     return true;
@@ -1396,7 +1423,7 @@ hipError_t amt_launch_march(hipStream_t stream, const AmtParams<T> &p)
     if (p.i1 < p.i0 || p.j1 < p.j0) return hipSuccess;
     const AmtMarchPlan<T> *pl = amt_march_plan<T>(p);
     if (!pl) return hipErrorNotSupported;
-    pl->entry->launch[pl->full](stream, p, pl->grid, pl->nw, pl->lds);
+    pl->entry->launch[pl->which](stream, p, pl->grid, pl->nw, pl->lds);
     // the kernel the calling thread LAUNCHED last (a slab's one-row edge launch does not rename its interior kernel)
     if (p.edges != 1 && strcmp(g_march_last, pl->label) != 0) snprintf(g_march_last, sizeof g_march_last, "%s", pl->label);
     return hipGetLastError();
@@ -1411,9 +1438,11 @@ extern "C" int amt_march_selectable(char *buf, int cap)
     auto add = [&](const char *t, const AmtMarchShape &q) {
         char line[160];
         for (int full = 0; full < (amt_march_full_build_ok(t[0] == 'd' ? 8 : 4, q) ? 2 : 1); ++full) {
-            snprintf(line, sizeof line, "amt_march_kernel<%s, %d, %d, %d, %d, %s, %s, %d>\n", t, q.vw, q.kpt, q.hl, q.xd,
-                     full ? "true" : "false", q.dma ? "true" : "false", q.wm);
-            if (s.find(line) == std::string::npos) s += line;
+            for (int ntl : {AMT_NT_LOAD, 0}) {                     // the two cache policies of the once-read streams
+                snprintf(line, sizeof line, "amt_march_kernel<%s, %d, %d, %d, %d, %s, %s, %d, %d>\n", t, q.vw, q.kpt, q.hl, q.xd,
+                         full ? "true" : "false", q.dma ? "true" : "false", q.wm, ntl);
+                if (s.find(line) == std::string::npos) s += line;
+            }
         }
     };
     for (int nk = 1; nk <= 400; ++nk)

@@ -4,8 +4,11 @@
 #include "amt_internal.h"
 #include <chrono>
 #include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
+#include <vector>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -262,14 +265,14 @@ int amt_keep_flush(HostWorkspace &ws)
 }
 }  // namespace
 
-extern "C" int amt_host_release(void)
+static int host_release_local()
 {
     const int rc = amt_keep_flush(tl_workspace);              // what only the device holds comes down before the buffers go
     tl_workspace.release();
     return rc;
 }
 
-extern "C" int amt_host_cache_enable(int on)
+static int host_cache_enable_local(int on)
 {
     HostWorkspace &ws = tl_workspace;
     if (!on && ws.res.enabled && ws.device >= 0) {
@@ -285,13 +288,13 @@ extern "C" int amt_host_cache_enable(int on)
     return AMT_OK;
 }
 
-extern "C" int amt_host_cache_check(int on)
+static int host_cache_check_local(int on)
 {
     tl_workspace.res.check = on != 0;
     return AMT_OK;
 }
 
-extern "C" int amt_host_invalidate(const void *host_ptr)
+static int host_invalidate_local(const void *host_ptr)
 {
     // "the host array was rewritten": a cached input goes up again with the next call; for a deferred output the HOST
     // is the truth again (whatever the device still held for it is given up)
@@ -301,7 +304,7 @@ extern "C" int amt_host_invalidate(const void *host_ptr)
     return AMT_OK;                                            // an array that is not kept is uploaded anyway
 }
 
-extern "C" int amt_host_defer(const void *host_ptr, int on)
+static int host_defer_local(const void *host_ptr, int on)
 {
     HostWorkspace &ws = tl_workspace;
     HostWorkspace::Kept &k = ws.res;
@@ -328,7 +331,7 @@ extern "C" int amt_host_defer(const void *host_ptr, int on)
     return AMT_OK;
 }
 
-extern "C" int amt_host_fetch(const void *host_ptr)
+static int host_fetch_local(const void *host_ptr)
 {
     HostWorkspace &ws = tl_workspace;
     if (ws.device < 0) return AMT_OK;
@@ -342,7 +345,7 @@ extern "C" int amt_host_fetch(const void *host_ptr)
     return AMT_OK;
 }
 
-extern "C" int amt_host_stale(const void *host_ptr)
+static int host_stale_local(const void *host_ptr)
 {
     const HostWorkspace::Kept &k = tl_workspace.res;
     for (int r = HostWorkspace::NCACHE; r < HostWorkspace::NKEEP; ++r)
@@ -384,7 +387,7 @@ static bool amt_is_pinned(const void *ptr)
 extern "C" int amt_host_pin(void *ptr, size_t bytes)
 {
     if (!ptr) return amt_fail(AMT_ERR_INVALID_ARG, "null pointer");
-    AMT_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    AMT_HIP(hipHostRegister(ptr, bytes, hipHostRegisterPortable));       // page-locked for every device (amt_host_set_devices)
     return AMT_OK;
 }
 
@@ -467,13 +470,21 @@ static int amt_host_call(const AmtArgs<T> &h)
     // arena layout: [3-D inputs][3-D outputs][small outputs][small inputs] -- what comes down is
     // one contiguous range, and so is everything a packed call sends up
     HostWorkspace &ws = tl_workspace;
-    if (ws.device >= 0 && ws.device != device && ws.res.any_stale()) {
+    // Test hook (tests/test_gpu_20_host_cache.py, the one-GPU twin of the two-device test): AMT_TEST_PRETEND_DEVICE_CHANGE=n makes
+    // the n-th one-shot call of a thread behave as if the thread had moved to another device since its last call -- the workspace
+    // of the "old" device is given up exactly as prepare() gives it up, only the device number stays the same.
+    static thread_local long calls_of_this_thread = 0;
+    ++calls_of_this_thread;
+    const char *pretend_env = getenv("AMT_TEST_PRETEND_DEVICE_CHANGE");
+    const bool pretend_move = pretend_env && *pretend_env && atol(pretend_env) == calls_of_this_thread && ws.device >= 0;
+    if (ws.device >= 0 && (ws.device != device || pretend_move) && ws.res.any_stale()) {
         // the thread moved to another device: prepare() gives the old device's workspace up, and deferred outputs whose only
         // current copy lives there must come down to their host arrays first (nothing the device alone holds is ever dropped,
         // ADVICE r04) -- on the OLD device, whose streams still exist
         rc = amt_keep_flush(ws);
         if (rc != AMT_OK) return rc;
     }
+    if (pretend_move) ws.release();                           // what prepare() does when device != ws.device
     {
         const hipError_t e = ws.prepare(device, big_bytes + small_bytes);
         if (e == hipErrorOutOfMemory) return amt_fail(AMT_ERR_ALLOC, "hipMalloc of %zu bytes failed", big_bytes + small_bytes);
@@ -841,13 +852,258 @@ static int amt_host_call(const AmtArgs<T> &h)
     return rc;
 }
 
+// ---------------------------------------------------------------------------
+// One call, several devices: the j range of the tile fanned over device slots (amt_host_set_devices / AMT_ONESHOT_DEVICES).
+//
+// The reference's host call IS the multi-GPU call: advance_mu_t_no_async.cu:108-162 splits j over `GPUs` devices inside one
+// advance_mu_t(...), refills each device's halo rows from the HOST arrays (:135-160), launches and gathers per device
+// (:329-390).  Here the calling thread owns one WORKER THREAD per device slot; a call cuts jts..jte into contiguous pieces
+// (uneven where the rows do not divide) and every worker runs the ordinary one-shot call on its piece -- a tile of the same
+// domain, global ids..jde unchanged, so the window rule clips each piece as it clips the whole (module_small_step_em.f90:
+// 91-106), and the rows a piece reads across its edges come from the host arrays, as in the reference: no traffic between
+// the devices at all.  A worker is a host thread, so everything a thread keeps between calls (streams, arena, residency cache,
+// deferred outputs: HostWorkspace above) exists once per slot, on the slot's device, and the control calls (amt_host_cache_*,
+// amt_host_defer / _fetch / _stale / _invalidate / _release) are forwarded to every slot.  The host link is the bound of the
+// one-shot path: n devices on n links carry n times the rows.  Slots may name one device several
+// times (how the tests run on a one-GPU box).
+// ---------------------------------------------------------------------------
+void amt_march_note_kernel(const char *name);                 // amt_kernel_march.hip: what amt_march_last_kernel reports
+namespace {
+struct FanWorker {
+    int device = 0;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, stop = false;
+    int rc = AMT_OK;
+    std::string error, kernel;
+
+    void main()
+    {
+        (void)hipSetDevice(device);
+        for (;;) {
+            std::function<int()> f;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || has_job; });
+                if (!has_job) return;                          // stop: the thread's workspace is released by its destructor
+                f = job;
+            }
+            (void)hipSetDevice(device);
+            const int r = f();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                rc = r;
+                error = r == AMT_OK ? "" : amt_last_error();
+                kernel = amt_march_last_kernel();
+                has_job = false;
+                done = true;
+            }
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> f)
+    {
+        { std::lock_guard<std::mutex> lk(m); job = std::move(f); has_job = true; done = false; }
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+        return rc;
+    }
+};
+
+struct Fan {
+    std::vector<std::unique_ptr<FanWorker>> slots;
+    bool env_checked = false;
+    bool active() const { return !slots.empty(); }
+
+    // every slot runs f on its own thread; the first failure (by slot) is the call's, with its text
+    int all(const std::function<int(int slot)> &f, int *max_rc = nullptr)
+    {
+        for (size_t q = 0; q < slots.size(); ++q) slots[q]->post([f, q] { return f((int)q); });
+        int first = AMT_OK, worst = 0;
+        std::string text;
+        for (auto &w : slots) {
+            const int rc = w->wait();
+            if (max_rc) {                                      // amt_host_stale: -1 (undefined) beats 1 (stale) beats 0
+                if (rc < 0) worst = -1;
+                else if (rc > 0 && worst == 0) worst = 1;
+            } else if (rc != AMT_OK && first == AMT_OK) {
+                first = rc;
+                text = w->error;
+            }
+        }
+        if (max_rc) { *max_rc = worst; return AMT_OK; }
+        return first == AMT_OK ? AMT_OK : amt_fail(first, "%s", text.c_str());
+    }
+    int stop()
+    {
+        if (slots.empty()) return AMT_OK;
+        const int rc = all([](int) { return host_release_local(); });     // what only a slot's device holds comes down first
+        for (auto &w : slots) {
+            { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+        slots.clear();
+        return rc;
+    }
+    int start(int n, const int *ids)
+    {
+        int ndev = 0;
+        AMT_HIP(hipGetDeviceCount(&ndev));
+        for (int q = 0; q < n; ++q)
+            if (ids[q] < 0 || ids[q] >= ndev) return amt_fail(AMT_ERR_INVALID_ARG, "amt_host_set_devices: device %d of %d visible", ids[q], ndev);
+        int rc = stop();
+        if (rc == AMT_OK) rc = host_release_local();           // what the calling thread's own device copies hold comes down: the slots read the host arrays
+        if (rc != AMT_OK) return rc;
+        const HostWorkspace::Kept &mine = tl_workspace.res;    // the calling thread's settings go to every slot
+        for (int q = 0; q < n; ++q) {
+            std::unique_ptr<FanWorker> w(new (std::nothrow) FanWorker);
+            if (!w) { (void)stop(); return amt_fail(AMT_ERR_ALLOC, "host allocation failed"); }
+            w->device = ids[q];
+            FanWorker *raw = w.get();
+            w->th = std::thread([raw] { raw->main(); });
+            slots.push_back(std::move(w));
+        }
+        const bool enabled = mine.enabled, check = mine.check, defer_all = mine.defer_all;
+        std::vector<const void *> deferred(mine.defer_ptr, mine.defer_ptr + mine.ndefer);
+        return all([=](int) {
+            int r = host_cache_enable_local(enabled);
+            if (r == AMT_OK) r = host_cache_check_local(check);
+            if (r == AMT_OK && defer_all) r = host_defer_local(nullptr, 1);
+            for (const void *q : deferred)
+                if (r == AMT_OK) r = host_defer_local(q, 1);
+            return r;
+        });
+    }
+    // A thread that ends takes its slots down in order (deferred outputs come down first).  The MAIN thread's destructor runs at
+    // process exit, possibly after the HIP runtime's own teardown: there the workers are left to the operating system, like
+    // the main thread's HostWorkspace.
+    ~Fan()
+    {
+        if ((long)syscall(SYS_gettid) != (long)getpid()) { (void)stop(); return; }
+        for (auto &w : slots) { w->th.detach(); (void)w.release(); }
+    }
+};
+thread_local Fan tl_fan;
+
+// AMT_ONESHOT_DEVICES="0,1,2" | "all": the device slots of every thread that has not called amt_host_set_devices (hosts that
+// cannot add a call: the Fortran drop-in module is one CALL).  Read on a thread's first one-shot or control call.
+int fan_from_env()
+{
+    Fan &fan = tl_fan;
+    if (fan.env_checked) return AMT_OK;
+    fan.env_checked = true;
+    const char *e = getenv("AMT_ONESHOT_DEVICES");
+    if (!e || !*e) return AMT_OK;
+    std::vector<int> ids;
+    if (!strcmp(e, "all")) {
+        int ndev = 0;
+        AMT_HIP(hipGetDeviceCount(&ndev));
+        for (int d = 0; d < ndev; ++d) ids.push_back(d);
+    } else {
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q) return amt_fail(AMT_ERR_INVALID_ARG, "AMT_ONESHOT_DEVICES must be a comma-separated list of device numbers or 'all', not '%s'", e);
+            ids.push_back((int)v);
+            q = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') return amt_fail(AMT_ERR_INVALID_ARG, "AMT_ONESHOT_DEVICES must be a comma-separated list of device numbers or 'all', not '%s'", e);
+        }
+    }
+    if (ids.empty()) return AMT_OK;
+    if (ids.size() == 1) {                                     // one device: no fan, the calls of this thread go there
+        AMT_HIP(hipSetDevice(ids[0]));
+        return AMT_OK;
+    }
+    return fan.start((int)ids.size(), ids.data());
+}
+
+template <typename T>
+int amt_host_call_fanned(const AmtArgs<T> &h)
+{
+    Fan &fan = tl_fan;
+    // the preconditions of the whole tile, once, on the calling thread (host arithmetic): a bad call fails before any piece runs
+    {
+        AmtParams<T> p;
+        AmtWindow w;
+        bool empty = false;
+        const int rc = amt_build_params(h, p, w, &empty);
+        if (rc != AMT_OK || empty) return rc;
+    }
+    const int n = (int)fan.slots.size();
+    const long rows = (long)h.jte - h.jts + 1;
+    const int rc = fan.all([&h, n, rows](int q) {
+        const int lo = h.jts + (int)((rows * q) / n), hi = h.jts + (int)((rows * (q + 1)) / n) - 1;
+        if (hi < lo) return (int)AMT_OK;                       // fewer rows than slots: this one has none
+        AmtArgs<T> mine = h;
+        mine.jts = lo;
+        mine.jte = hi;
+        return amt_host_call<T>(mine);
+    });
+    if (rc == AMT_OK && !fan.slots[0]->kernel.empty()) amt_march_note_kernel(fan.slots[0]->kernel.c_str());
+    return rc;
+}
+}  // namespace
+
+extern "C" int amt_host_set_devices(int n, const int *device_ids)
+{
+    if (n < 0 || (n > 0 && !device_ids) || n > 64) return amt_fail(AMT_ERR_INVALID_ARG, "bad device list");
+    tl_fan.env_checked = true;                                 // an explicit call outranks AMT_ONESHOT_DEVICES
+    if (n == 0) return tl_fan.stop();
+    return tl_fan.start(n, device_ids);
+}
+
+extern "C" int amt_host_devices(int *device_ids, int cap)
+{
+    const Fan &fan = tl_fan;
+    for (int q = 0; q < (int)fan.slots.size() && q < cap && device_ids; ++q) device_ids[q] = fan.slots[q]->device;
+    return (int)fan.slots.size();
+}
+
+#define AMT_FAN_OR_LOCAL(local_call)                                              \
+    do {                                                                           \
+        if (int rc_ = fan_from_env()) return rc_;                                  \
+        if (tl_fan.active()) {                                                     \
+            const int rc_ = tl_fan.all([=](int) { return local_call; });           \
+            if (rc_ != AMT_OK) return rc_;                                         \
+        }                                                                          \
+        return local_call;                                                         \
+    } while (0)
+
+extern "C" int amt_host_cache_enable(int on) { AMT_FAN_OR_LOCAL(host_cache_enable_local(on)); }
+extern "C" int amt_host_cache_check(int on) { AMT_FAN_OR_LOCAL(host_cache_check_local(on)); }
+extern "C" int amt_host_invalidate(const void *host_ptr) { AMT_FAN_OR_LOCAL(host_invalidate_local(host_ptr)); }
+extern "C" int amt_host_defer(const void *host_ptr, int on) { AMT_FAN_OR_LOCAL(host_defer_local(host_ptr, on)); }
+extern "C" int amt_host_fetch(const void *host_ptr) { AMT_FAN_OR_LOCAL(host_fetch_local(host_ptr)); }
+extern "C" int amt_host_release(void) { AMT_FAN_OR_LOCAL(host_release_local()); }
+extern "C" int amt_host_stale(const void *host_ptr)
+{
+    (void)fan_from_env();
+    int worst = host_stale_local(host_ptr);
+    if (tl_fan.active()) {
+        int w = 0;
+        (void)tl_fan.all([=](int) { return host_stale_local(host_ptr); }, &w);
+        if (w < 0 || worst < 0) worst = -1;
+        else if (w > 0) worst = 1;
+    }
+    return worst;
+}
+
 extern "C" int amt_advance_mu_t_f32(AMT_SIG(float))
 {
     AMT_PACK_ARGS(float)
-    return amt_host_call<float>(a);
+    if (int rc = fan_from_env()) return rc;
+    return tl_fan.active() ? amt_host_call_fanned<float>(a) : amt_host_call<float>(a);
 }
 extern "C" int amt_advance_mu_t_f64(AMT_SIG(double))
 {
     AMT_PACK_ARGS(double)
-    return amt_host_call<double>(a);
+    if (int rc = fan_from_env()) return rc;
+    return tl_fan.active() ? amt_host_call_fanned<double>(a) : amt_host_call<double>(a);
 }

@@ -40,6 +40,7 @@ program advance_mu_t_driver
   integer(kind=8) :: c0, c1, cmid, hz
   real(kind=8) :: cells, secs
   integer :: nbad, ndef, ntune
+  integer(c_int) :: nslots, slot_ids(16)
   real(c_float) :: tune_ms(8)
 
   ni = 64; nk = 40; nj = 64; nsweeps = 5; outdir = ' '; iflag = 0      ! BASELINE.json configs[0]
@@ -155,6 +156,8 @@ program advance_mu_t_driver
   ! the first call creates this thread's device workspace (streams, events, arena), which later calls reuse
   secs = real(cmid - c0, 8) / real(hz, 8)
   print '(a,f10.4,a)', 'one-shot host path:   first call ', secs * 1.0d3, ' ms (creates the device workspace)'
+  nslots = amt_host_devices(slot_ids, 16_c_int)             ! AMT_ONESHOT_DEVICES="0,1,..." | "all": one call, several devices
+  if (nslots > 0) print '(a,i0,a,16(1x,i0))', 'one-shot host path:   every call fans its rows over ', nslots, ' device slot(s):', slot_ids(1:nslots)
   if (nsweeps > 1) then
      secs = real(c1 - cmid, 8) / real(hz, 8)
      print '(a,i0,a,f10.4,a,f12.1,a)', 'one-shot host path:   ', nsweeps - 1, ' calls,  ', secs * 1.0d3 / (nsweeps - 1), &

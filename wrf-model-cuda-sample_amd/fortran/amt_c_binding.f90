@@ -57,6 +57,21 @@ MODULE amt_c_binding
          type(c_ptr), value :: ptr
          integer(c_int) :: rc
       end function
+      ! one call, several devices: the one-shot calls of this thread fan their tile's rows jts..jte over n device slots (ids may
+      ! repeat), halo rows from the host arrays -- what the reference's own host call does (advance_mu_t_no_async.cu:108-162);
+      ! n = 0 turns it off.  AMT_ONESHOT_DEVICES="0,1,2" | "all" in the environment does the same without a call.
+      function amt_host_set_devices(n, device_ids) bind(C, name="amt_host_set_devices") result(rc)
+         import :: c_int
+         integer(c_int), value :: n
+         integer(c_int), intent(in) :: device_ids(*)
+         integer(c_int) :: rc
+      end function
+      function amt_host_devices(device_ids, cap) bind(C, name="amt_host_devices") result(n)
+         import :: c_int
+         integer(c_int), intent(out) :: device_ids(*)
+         integer(c_int), value :: cap
+         integer(c_int) :: n
+      end function
       ! free the device workspace the one-shot calls of this thread keep between calls
       function amt_host_release() bind(C, name="amt_host_release") result(rc)
          import :: c_int

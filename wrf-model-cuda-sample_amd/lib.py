@@ -78,6 +78,8 @@ SYMBOLS = {
     "amt_host_pin": (_I, [_P, ctypes.c_size_t]),
     "amt_host_unpin": (_I, [_P]),
     "amt_host_release": (_I, []),
+    "amt_host_set_devices": (_I, [_I, ctypes.POINTER(_I)]),
+    "amt_host_devices": (_I, [ctypes.POINTER(_I), _I]),
     "amt_host_cache_enable": (_I, [_I]),
     "amt_host_cache_check": (_I, [_I]),
     "amt_host_invalidate": (_I, [_P]),
@@ -118,6 +120,7 @@ SYMBOLS = {
     "amt_march_rows_for": (_I, [ctypes.c_long, _I, _I, ctypes.c_long, _I, _I]),
     "amt_march_set_xchunk": (_I, [_I]),
     "amt_march_set_beside": (_I, [_I, _I]),
+    "amt_march_set_stream_policy": (_I, [_I]),
     "amt_march_last_kernel": (ctypes.c_char_p, []),
     "amt_march_selectable": (_I, [ctypes.c_char_p, _I]),
 }
