@@ -32,7 +32,8 @@ for name in ("bench_plain", "bench_trace"):
             m = re.search(r"\[amt march\].*-> (amt_march_kernel<[^>]*>) (FULL|ragged): (\d+) waves, (\d+) B LDS, (\d+) tiles x (\d+) blocks of (\d+) rows", line)
             if m:
                 full = "true" if m.group(2) == "FULL" else "false"
-                PLAN[m.group(1).replace("FULL", full)] = tuple(int(x) for x in m.groups()[2:])
+                # the launcher's label -> the demangled name rocprofv3 prints (FULL / ragged and the cache policy are template arguments)
+                PLAN[m.group(1).replace("FULL", full).replace(", nt>", ", 1>").replace(", cached>", ", 0>")] = tuple(int(x) for x in m.groups()[2:])
 
 
 def rows(pattern):
