@@ -7,11 +7,16 @@
 A "step" is one advance_mu_t sweep (one acoustic sub-step's call) over the whole
 4096 x 60 x 4096 fp64 domain (BASELINE.json configs[2]/[3]); inputs are resident in HBM before
 the timed region.  With N > 1 the SAME domain is split into N j-slabs (strong scaling), each
-rank trades its one-row input halos every sweep (--transport rccl: ncclSend/ncclRecv; ipc: peer copies between
-processes, which may share one device) while its interior rows compute.  Default N > 1 stepper: the native C++ runtime behind the C-ABI (amt_slab_*, the path a
-Fortran host calls; patch.NativeSlabStepper hands it pointers); --stepper torch runs the same
-schedule through torch.distributed P2P ops (patch.SlabStepper) as a cross-check.  Both start from
-NaN-poisoned halo rows and are verified against the oracle after the first sweep.
+rank trades its one-row input halos every sweep while its interior rows compute.
+
+N > 1 is a FIRST-CONTACT LADDER (see the block comment above supervise()): the process the launcher starts per rank is a
+supervisor that never touches a GPU; every transport is a rung run in fresh child processes under --rung-timeout -- rccl
+(ncclSend/ncclRecv inside the C++ runtime amt_slab_*, the path a Fortran host calls), then ipc (peer copies + a shared-memory
+mailbox between processes, which may share one device), torch.distributed P2P over RCCL only if neither ran.  --transport both
+(default) times BOTH: `value` is RCCL's (north_star's transport) when its rung ran; `transports`, `ladder`, `preflight` say the
+rest.  Every rung starts from NaN-poisoned halo rows, verifies its first sweep against the oracle and a later sweep after NEW
+values in the exchanged fields and re-poisoned halos (an exchange that delivers once does not pass).  --stepper torch /
+--backend gloo are the in-process bring-up modes.
 
 Output keys beyond the driver's contract:
   roofline      algorithmic HBM bytes of one sweep (W*NI*NJ*(11*NK+14))
@@ -19,6 +24,9 @@ Output keys beyond the driver's contract:
   cpu_baseline  the fastest CPU path -- the build's Fortran-90 restatement or the C port, both j-tiled over the
                 host cores -- timed on the WHOLE domain where host memory and the leg's budget allow, else on a bounded
                 j-slab sample of it (rank 0, N=1; the record says which)
+  config.idim ... aligned, wrf_rows   (N = 1) the memory layout of the timed state (rows padded to whole 128-byte lines), and the same
+                sweeps + PMC passes on WRF's own unpadded extents ims:ime = 0:NI+1 in the same run
+  transports, ladder, preflight   (N > 1) every rung's outcome; per-rank roofline figures against 8 TB/s x N
   placement     the bench state is allocated by amt_domain_create (the product call a Fortran / C host makes once), whose
                 default placement sampling keeps the fastest of 4 allocations of the state: `value` is therefore what a
                 once-allocating host of the library gets; config.placement_probe_ms lists every allocation's sweep time
@@ -1438,25 +1446,32 @@ def run_rung_child(a, kind, env, timeout):
     argv = [sys.executable, str(Path(sys.argv[0]).resolve())] + [x for x in sys.argv[1:]] + ["--rung-child", kind]
     t0 = time.perf_counter()
     p = subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, preexec_fn=_set_pdeathsig)
-    err_tail = []
+    err_tail, out_chunks = [], []
 
-    def pump():
+    def pump_err():                          # the child's stderr goes on to this rank's stderr, tagged with the rung
         for line in iter(p.stderr.readline, b""):
             text = line.decode(errors="replace")
             err_tail.append(text)
             del err_tail[:-30]
             sys.stderr.write(f"[{kind}] " + text)
             sys.stderr.flush()
-    th = threading.Thread(target=pump, daemon=True)
-    th.start()
+
+    def pump_out():                          # its stdout is kept: the record is in there
+        for chunk in iter(lambda: p.stdout.read(65536), b""):
+            out_chunks.append(chunk)
+    pumps = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for th in pumps:
+        th.start()
     timed_out = False
     try:
-        out, _ = p.communicate(timeout=timeout)
+        p.wait(timeout=timeout)
     except subprocess.TimeoutExpired:
         timed_out = True
-        p.kill()
-        out, _ = p.communicate()
-    th.join(timeout=2)
+        p.kill()                             # this child, by its pid
+        p.wait()
+    for th in pumps:
+        th.join(timeout=5)
+    out = b"".join(out_chunks)
     seconds = round(time.perf_counter() - t0, 1)
     rec = None
     text = (out or b"").decode(errors="replace")

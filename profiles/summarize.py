@@ -101,6 +101,8 @@ dom = max((k for k in dur if "amt_" in k and "synth" not in k and "calib" not in
 if line and dom and dom in out["kernels"] and "FETCH_SIZE" in out["kernels"][dom] and "WRITE_SIZE" in out["kernels"][dom]:
     cfg = line["config"]
     key = f"{cfg['ni']}x{cfg['nk']}x{cfg['nj']}_{line['dtype']}_n{line['n_gpus']}"
+    if cfg.get("aligned") is False:                      # WRF's own unpadded rows (bench.py --align-elems 1): a key of its own
+        key += f"_rows{cfg['idim']}"
     fetch = out["kernels"][dom]["FETCH_SIZE"]["mean_per_launch"]
     write = out["kernels"][dom]["WRITE_SIZE"]["mean_per_launch"]
     path = os.path.join(here, "hbm_traffic.json")
@@ -111,6 +113,8 @@ if line and dom and dom in out["kernels"] and "FETCH_SIZE" in out["kernels"][dom
                             f"doubled per the gfx950 calibration in profiles/README.md)",
                   "kernel": dom, "kernel_avg_us": round(sum(dur[dom]) / len(dur[dom]), 1),
                   "algorithmic_bytes": line["roofline"]["algorithmic_bytes_per_launch"]}
+    if cfg.get("aligned") is False:
+        table[key]["layout"] = f"WRF's own unpadded rows (bench.py --align-elems 1: {cfg['idim']}-element rows)"
     json.dump(table, open(path, "w"), indent=1)
     print("hbm_traffic.json:", key, table[key])
 print(open(os.path.join(here, f"{tag}_kernel_stats.csv")).read())
