@@ -133,6 +133,16 @@ def test_3x2_processes_uneven_patches_fp32_unaligned_rows(pkg, oracle, tmp_path)
     _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 3, 2, dims, "f32", 3, False, 1)
 
 
+def test_4x2_processes_the_target_world_of_eight_on_one_device(pkg, oracle, tmp_path):
+    """Eight real processes -- the node's world size -- as 4 x 2 patches on cuda:0: the two middle columns of patches have
+    neighbours on three or four sides; uneven in both directions (203 columns over 4, 45 rows over 2), specified boundaries, four
+    sweeps with new inputs and re-poisoned halos before each but the first."""
+    dims = (203, 16, 45)
+    outs = run_grid_ranks(tmp_path, 4, 2, dims, sweeps=4, specified=True)
+    assert all("transport ipc, ranks seen 8" in o for o in outs), outs
+    _check_against_the_unsplit_oracle(pkg, oracle, tmp_path, 4, 2, dims, "f64", 4, True, 32)
+
+
 @pytest.mark.parametrize("real", ["f64", "f32"])
 def test_fortran_host_2x2_processes_over_the_ipc_transport(pkg, oracle, tmp_path, real):
     """The i x j decomposition from a FORTRAN host (fortran/advance_mu_t_grid_driver.f90: amt_domain_create, amt_grid_create,
