@@ -164,6 +164,7 @@ struct HostWorkspace {
     }
 };
 thread_local HostWorkspace tl_workspace;
+thread_local long tl_oneshot_calls = 0;                       // one-shot calls of this thread, either precision (test hook below)
 struct WorkspaceScope {
     HostWorkspace &ws;
     ~WorkspaceScope() { ws.finish(); }
@@ -473,8 +474,7 @@ static int amt_host_call(const AmtArgs<T> &h)
     // Test hook (tests/test_gpu_20_host_cache.py, the one-GPU twin of the two-device test): AMT_TEST_PRETEND_DEVICE_CHANGE=n makes
     // the n-th one-shot call of a thread behave as if the thread had moved to another device since its last call -- the workspace
     // of the "old" device is given up exactly as prepare() gives it up, only the device number stays the same.
-    static thread_local long calls_of_this_thread = 0;
-    ++calls_of_this_thread;
+    const long calls_of_this_thread = ++tl_oneshot_calls;
     const char *pretend_env = getenv("AMT_TEST_PRETEND_DEVICE_CHANGE");
     const bool pretend_move = pretend_env && *pretend_env && atol(pretend_env) == calls_of_this_thread && ws.device >= 0;
     if (ws.device >= 0 && (ws.device != device || pretend_move) && ws.res.any_stale()) {
