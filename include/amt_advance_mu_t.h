@@ -25,11 +25,12 @@
  *    window plus its one-cell input halo (i-1, i+1, j-1, j+1) inside memory.
  *    Level count: a column's k chains live in LDS, which holds 320 levels in
  *    fp64 and 640 in fp32 (AMT_ERR_PRECONDITION beyond; WRF runs 30..150).
- *    SPEED CLIFF: the production kernel (AMT_VARIANT_MARCH) keeps four level-by-column
+ *    SPEED CLIFF (a step since r06): the production kernel (AMT_VARIANT_MARCH) keeps four level-by-column
  *    buffers of a tile in the CU's 160 KB of LDS, which ends at 240 levels in fp64 and
  *    264 in fp32 (16-column tiles; a fifth level per lane does not fit).  Beyond that
- *    AMT_VARIANT_AUTO falls back to the column kernel, which is correct but re-reads its
- *    neighbours and runs about 8x slower (9 % against 57-70 % of the HBM roofline); the first such call of a process says so
+ *    AMT_VARIANT_AUTO falls back to the column kernel, which re-reads its neighbours and evaluates dvdxi twice instead of
+ *    keeping it (nothing in LDS): about 0.41 of the HBM roofline against 0.61-0.75 for the march kernel (until r06: 0.09, one
+ *    wave per compute unit under a 150 KB LDS column); the first such call of a process says so
  *    on stderr (AMT_QUIET=1 suppresses it).
  *  - Return value: AMT_OK or an amt_status code; nothing ever calls exit()
  *    (the reference's wrapper prints and exit(1)s, advance_mu_t_no_async.cu:22-32,

@@ -129,13 +129,17 @@ static int amt_launch(hipStream_t stream, int variant, const AmtParams<T> &p)
 {
     if (variant == AMT_VARIANT_AUTO) {
         variant = amt_march_supported(p) ? AMT_VARIANT_MARCH : AMT_VARIANT_COLUMN;
+        // fp32 beyond 264 levels: the only march shapes left are the one-column-per-lane register builds (<float,1,8,4,...>: 0.29-0.31
+        // of the HBM roofline), which the column kernel's recompute flavour beats (0.41; profiles/r06_tall_columns.md)
+        if (sizeof(T) == 4 && p.nk > 264) variant = AMT_VARIANT_COLUMN;
         if (variant == AMT_VARIANT_COLUMN && p.nk > (sizeof(T) == 8 ? 240 : 264)) {
-            // the speed cliff of the header (beyond 240 levels in fp64 / 264 in fp32 the march kernel's tile no longer fits the LDS):
+            // the speed step of the header (beyond 240 levels in fp64 / 264 in fp32 the march kernel's tile no longer fits the LDS):
             // said once per process on stderr, never silently (AMT_QUIET=1 to suppress)
             static std::atomic<bool> said{false};
             if (!said.exchange(true) && !getenv("AMT_QUIET"))
-                fprintf(stderr, "amt: advance_mu_t with %d levels runs on the column kernel (about 8x slower than the march kernel, which "
-                                "holds at most 240 levels in fp64 / 264 in fp32); see include/amt_advance_mu_t.h, \"SPEED CLIFF\"\n", p.nk);
+                fprintf(stderr, "amt: advance_mu_t with %d levels runs on the column kernel (about 0.41 of the HBM roofline against 0.61-0.75 for "
+                                "the march kernel, which holds at most 240 levels in fp64 / 264 in fp32); see include/amt_advance_mu_t.h, "
+                                "\"SPEED CLIFF\"\n", p.nk);
         }
     }
     hipError_t e;

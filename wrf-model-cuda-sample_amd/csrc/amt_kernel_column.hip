@@ -15,14 +15,22 @@
 // sequential k order of the dmdt sum and of the ww recurrence).
 //
 // No __syncthreads(): a lane only ever reads the LDS words it wrote itself.
+//
+// RECOMPUTE: the LDS column is nk * 64 * sizeof(T) bytes per wave -- 30 KB at 60 fp64 levels, 150 KB at 300, which leaves ONE wave per
+// compute unit (AUTO falls back to this kernel beyond the march kernel's 240 / 264 levels: 9 % of the HBM roofline until r06).  With
+// RECOMPUTE nothing is kept: pass 2 evaluates dvdxi(k) again from the same operands with the same expression -- the same bits -- at the
+// price of reading u_1 and v_1 a second time (u and v are read by pass 2 anyway), and the occupancy is bounded by registers only.
+// Measured (profiles/r06_tall_columns.md, 4096 columns wide): 300 fp64 levels 38.0 -> 8.4 ms (0.09 -> 0.41 of 8 TB/s), 60 levels 8.0 ->
+// 6.3 ms, 20 levels 3.7 -> 4.3 ms: the launcher takes it where the LDS column is larger than 16 KB (more than 32 fp64 / 64 fp32 levels).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "amt_params.h"
 
-template <typename T>
+template <typename T, bool RECOMPUTE>
 __global__ __launch_bounds__(64) void amt_column_kernel(const AmtParams<T> p, const int ntile_i)
 {
     extern __shared__ __align__(16) unsigned char amt_smem[];
-    T *dv = reinterpret_cast<T *>(amt_smem);          // [nk][64]
+    T *dv = reinterpret_cast<T *>(amt_smem);          // [nk][64] (unused with RECOMPUTE)
 
     const int lane = threadIdx.x;
     const int tile = blockIdx.x % ntile_i;
@@ -47,16 +55,20 @@ __global__ __launch_bounds__(64) void amt_column_kernel(const AmtParams<T> p, co
     const T *dnw = p.dnw + p.k1, *fnm = p.fnm + p.k1, *fnp = p.fnp + p.k1, *rdnw = p.rdnw + p.k1;
     // dnw[k-1] etc. below: index 0 is Fortran level 1
 
-    // ---- pass 1: divergence and column integral (:140-149) ----
-    T dmdt = T(0);
-    for (int k = 0; k < nk; ++k) {
-        const long c = c3 + (long)k * idim;
-        const T d = msftx * msfty * (
+    // dvdxi(i,k,j), :141-146
+    auto dvdxi = [&](long c) -> T {
+        return msftx * msfty * (
               rdy * ( (p.v[c + js] + muv_jp * p.v_1[c + js] * mvx_jp)
                     - (p.v[c     ] + muv_j  * p.v_1[c     ] * mvx_j ) )
             + rdx * ( (p.u[c + 1] + muu_ip * p.u_1[c + 1] / msfuy_ip)
                     - (p.u[c    ] + muu_i  * p.u_1[c    ] / msfuy_i ) ));
-        dv[k * 64 + lane] = d;
+    };
+
+    // ---- pass 1: divergence and column integral (:140-149) ----
+    T dmdt = T(0);
+    for (int k = 0; k < nk; ++k) {
+        const T d = dvdxi(c3 + (long)k * idim);
+        if (!RECOMPUTE) dv[k * 64 + lane] = d;
         dmdt = dmdt + dnw[k] * d;
     }
 
@@ -82,7 +94,8 @@ __global__ __launch_bounds__(64) void amt_column_kernel(const AmtParams<T> p, co
         const long c = c3 + (long)k * idim;
         T wout_n = T(0), wd_n = T(0), t1_n = T(0);
         if (k + 1 < nk) {
-            ww_un  = ww_un - dnw[k] * (dmdt + dv[k * 64 + lane] + mu_tend) / msfty;   // :161
+            const T dv_k = RECOMPUTE ? dvdxi(c) : dv[k * 64 + lane];
+            ww_un  = ww_un - dnw[k] * (dmdt + dv_k + mu_tend) / msfty;                 // :161
             wout_n = ww_un - p.ww_1[c + idim];                                         // :170
             t1_n   = p.t_1[c + idim];
             wd_n   = wout_n * (fnm[k + 1] * t1_n + fnp[k + 1] * t1_k);                 // :227
@@ -123,22 +136,29 @@ hipError_t amt_launch_column(hipStream_t stream, const AmtParams<T> &p)
     q.msfvx_inv += shift; q.msftx += shift; q.msfty += shift;
     q.i0 -= (int)shift; q.i1 -= (int)shift;
     const size_t lds = (size_t)(p.nk > 0 ? p.nk : 1) * 64 * sizeof(T);
-    // one dvdxi column per lane in LDS: 160 KB hold 320 levels in fp64, 640 in fp32
+    // one dvdxi column per lane in LDS: 160 KB hold 320 levels in fp64, 640 in fp32 (the header's level limit)
     if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
+    const unsigned grid = (unsigned)((long)ntile_i * nj);
+    // tall columns: nothing in LDS, dvdxi evaluated twice (see the head of this file); AMT_COLUMN_RECOMPUTE=0|1 forces either
+    const char *force = getenv("AMT_COLUMN_RECOMPUTE");          // read per launch: a test flips it in-process
+    const bool recompute = force && *force ? atoi(force) != 0 : lds > 16 * 1024;
+    if (recompute) {
+        hipLaunchKernelGGL((amt_column_kernel<T, true>), dim3(grid), dim3(64), 0, stream, q, ntile_i);
+        return hipGetLastError();
+    }
     if (lds > 64 * 1024) {
         // beyond 64 KB of dynamic LDS a kernel has to be allowed to (per device, once)
         static unsigned granted = 0;
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!(granted >> (dev & 31) & 1u)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_column_kernel<T>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(amt_column_kernel<T, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             granted |= 1u << (dev & 31);
         }
     }
-    const unsigned grid = (unsigned)((long)ntile_i * nj);
-    hipLaunchKernelGGL(amt_column_kernel<T>, dim3(grid), dim3(64), lds, stream, q, ntile_i);
+    hipLaunchKernelGGL((amt_column_kernel<T, false>), dim3(grid), dim3(64), lds, stream, q, ntile_i);
     return hipGetLastError();
 }
 
