@@ -1188,6 +1188,13 @@ def preflight_child(a):
     ndev = torch.cuda.device_count()
     rec["devices"] = ndev
     rec["device_name"] = torch.cuda.get_device_name(0)
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if local_rank >= ndev and not a.share_gpu:
+        # fewer devices than ranks: say so NOW (every rung would otherwise wait --comm-timeout for the ranks that cannot come)
+        rec.update(ok=False, error=f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible: one GPU per rank (--share-gpu maps the ranks onto "
+                                   "the visible devices: a correctness run over the IPC transport, never a scaling number)")
+        print(rec["error"], file=sys.stderr, flush=True)
+        _emit(rec, RUNG_FAIL_EXIT)
     if rank == 0:
         try:
             rec["peer_access"] = [[1 if i == j else int(torch.cuda.can_device_access_peer(i, j)) for j in range(ndev)] for i in range(ndev)]

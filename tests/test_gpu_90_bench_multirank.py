@@ -217,3 +217,18 @@ def test_first_contact_ladder_rccl_only_falls_back_to_torch_and_then_reports_fai
     out = json.loads(lines[0])
     assert out["value"] is None and [x["rung"] for x in out["ladder"]] == ["preflight", "rccl", "torch-rccl"]
     assert not any(x["ok"] for x in out["ladder"][1:])
+
+
+def test_more_ranks_than_devices_without_share_gpu_fails_in_the_preflight_not_after_minutes():
+    """`bench.py --gpus 2` on a one-GPU box without --share-gpu: rank 1 has no device.  The preflight rung says so on every rank's
+    behalf and the launch ends non-zero at once -- no transport rung is left waiting --comm-timeout for a rank that cannot come."""
+    import time
+    if _gpus() >= 2:
+        pytest.skip("two devices visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--launch-timeout", "300"] + SMALL,
+                       capture_output=True, text=True, timeout=400, env=env, cwd=str(ROOT))
+    assert r.returncode != 0 and "only 1 GPU(s) visible" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 120
