@@ -1237,7 +1237,7 @@ def rung_child(a):
     rec = {"rung": kind, "rank": rank, "ok": False}
     injected = _injected_outcome(kind, rank)
     if injected == "hang":
-        print(f"rank {rank} rung {kind}: hanging (injected)", file=sys.stderr, flush=True)
+        print(f"rank {rank} rung {kind} pid {os.getpid()}: hanging (injected)", file=sys.stderr, flush=True)
         time.sleep(3600)
     if injected in ("refuse", "open_fails"):
         rec["error"] = ("ncclCommInitRank failed: invalid usage (injected)" if injected == "refuse"

@@ -120,3 +120,58 @@ def test_ladder_nothing_works_the_line_says_so_and_the_exit_code_is_not_zero():
 def test_single_transport_request_runs_one_rung():
     out, _ = _ladder({}, "--transport", "ipc", gpus=2)
     assert [x["rung"] for x in out["ladder"]] == ["preflight", "ipc"] and out["value_transport"] == "ipc"
+
+
+def test_no_rung_child_outlives_the_launch():
+    """The children of a rung hold the GPUs.  SIGTERM to the launcher while every rank's RCCL child hangs: the launcher ends the
+    supervisors (their process groups), and the children -- started with PR_SET_PDEATHSIG -- go with them; nothing is left behind
+    that could keep a device busy for the next job."""
+    import re
+    import signal
+    env = _env()
+    env["AMT_BENCH_TEST_RUNG_RCCL"] = "hang"
+    p = subprocess.Popen([sys.executable, str(SHIM), "--gpus", "2", "--cpu-dry-run", "--ni", "24", "--nk", "4", "--nj", "16", "--steps", "1",
+                          "--warmup", "1", "--launch-timeout", "300", "--rung-timeout", "250"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=str(ROOT))
+    pids, buf = [], ""
+    t_end = time.time() + 120
+    while len(pids) < 2 and time.time() < t_end:
+        line = p.stderr.readline()
+        buf += line
+        pids = [int(x) for x in re.findall(r"rung rccl pid (\d+): hanging", buf)]
+    assert len(pids) == 2, buf[-3000:]
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+            return True
+        except ProcessLookupError:
+            return False
+    assert all(alive(q) for q in pids)
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM
+    t_end = time.time() + 10
+    while any(alive(q) for q in pids) and time.time() < t_end:
+        time.sleep(0.2)
+    assert not any(alive(q) for q in pids), "a rung child outlived its supervisor"
+
+
+def test_ladder_under_the_torch_launcher_the_driver_command_line():
+    """The driver's own N > 1 command line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P <script> --gpus N ... -- the supervisors form their group through the launcher's store, the rung children
+    through file stores of their own."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(SHIM), "--gpus", "2", "--cpu-dry-run", "--ni", "40", "--nk", "6", "--nj", "21",
+                        "--steps", "2", "--warmup", "2"],
+                       capture_output=True, text=True, env=_env(), timeout=400, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["launched_by"] == "external launcher" and out["n_gpus"] == 2 and out["verified_vs_oracle"] is True
+    assert out["transports"]["rccl"]["ok"] and out["transports"]["ipc"]["ok"]
