@@ -868,6 +868,15 @@ void amt_exchange_bytes(const AmtExchange *x, size_t *sent, size_t *received)
     for (const AmtSeg &s : x->recvs) *received += s.bytes;
 }
 
+// workgroups per segment of the plain copy kernels (staging refresh, host-waited pull): both run with the chip to themselves (in
+// front of / behind the interior), and a 2 MB row per segment wants more than a handful -- 16 / 32 per segment (r05) against 64:
+// one rank of 8 in loopback 1.920 -> 1.909 ms per sweep, a 1024 x 1024 patch +19.0 -> +17.9 % (r06).  AMT_IPC_COPY_WGS overrides.
+static unsigned amt_copy_wgs(unsigned dflt)
+{
+    static const int env = [] { const char *e = getenv("AMT_IPC_COPY_WGS"); return e && *e ? atoi(e) : 0; }();
+    return env >= 1 && env <= 1024 ? (unsigned)env : dflt;
+}
+
 // IPC: refresh the staging copies of the send segments (the stream must be one on which the segments are final)
 static int amt_ipc_stage(AmtExchange *x, hipStream_t stream)
 {
@@ -878,7 +887,7 @@ static int amt_ipc_stage(AmtExchange *x, hipStream_t stream)
         g.dst[k] = static_cast<char *>(x->stage) + x->stage_off[k];
         g.bytes[k] = x->sends[k].bytes;
     }
-    hipLaunchKernelGGL(amt_xchg_pull, dim3(16, (unsigned)x->sends.size()), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(amt_xchg_pull, dim3(amt_copy_wgs(64), (unsigned)x->sends.size()), dim3(256), 0, stream, g);
     AMT_HIP(hipGetLastError());
     return AMT_OK;
 }
@@ -965,7 +974,7 @@ int amt_exchange_enqueue_pull(AmtExchange *x, hipStream_t stream)
     } else if (x->pull_kernel && !x->recvs.empty()) {
         AmtPullSegs g{};
         for (size_t r = 0; r < x->recvs.size(); ++r) { g.src[r] = x->recv_src[r]; g.dst[r] = x->recvs[r].ptr; g.bytes[r] = x->recvs[r].bytes; }
-        hipLaunchKernelGGL(amt_xchg_pull, dim3(32, (unsigned)x->recvs.size()), dim3(256), 0, stream, g);
+        hipLaunchKernelGGL(amt_xchg_pull, dim3(amt_copy_wgs(64), (unsigned)x->recvs.size()), dim3(256), 0, stream, g);
     } else {
         for (size_t r = 0; r < x->recvs.size(); ++r)
             AMT_HIP(hipMemcpyAsync(x->recvs[r].ptr, x->recv_src[r], x->recvs[r].bytes, amt_engine_copy_kind(), stream));
