@@ -26,18 +26,25 @@
 #include <stdlib.h>
 #include "amt_params.h"
 
+// A workgroup is up to AMT_COLUMN_ROWS waves (blockDim.x / 64: the launcher's choice): wave w takes row (blockIdx / ntile_i) * rows + w of the tile.  The waves do not talk to each
+// other; they share a compute unit and an XCD, so the rows j-1, j+1 a wave reads (t_1, v, v_1) are its siblings' own rows: fetched
+// once into that L2 instead of once per row from HBM (profiles/r06_tall_columns.md).
+#ifndef AMT_COLUMN_ROWS
+#define AMT_COLUMN_ROWS 4
+#endif
+
 template <typename T, bool RECOMPUTE>
-__global__ __launch_bounds__(64) void amt_column_kernel(const AmtParams<T> p, const int ntile_i)
+__global__ __launch_bounds__(64 * AMT_COLUMN_ROWS) void amt_column_kernel(const AmtParams<T> p, const int ntile_i)
 {
     extern __shared__ __align__(16) unsigned char amt_smem[];
-    T *dv = reinterpret_cast<T *>(amt_smem);          // [nk][64] (unused with RECOMPUTE)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T *dv = reinterpret_cast<T *>(amt_smem) + (size_t)wave * (size_t)(p.nk > 0 ? p.nk : 1) * 64;     // [nk][64] per wave (unused with RECOMPUTE)
 
-    const int lane = threadIdx.x;
     const int tile = blockIdx.x % ntile_i;
-    const int jrow = blockIdx.x / ntile_i;
+    const int jrow = (blockIdx.x / ntile_i) * (int)(blockDim.x >> 6) + wave;
     const int ii   = tile * 64 + lane;                // zero-based memory i
     const int jj   = p.j0 + jrow;                     // zero-based memory j
-    if (ii < p.i0 || ii > p.i1) return;
+    if (jj > p.j1 || ii < p.i0 || ii > p.i1) return;
 
     const long idim = p.idim;
     const long js   = p.jstride;
@@ -135,18 +142,22 @@ hipError_t amt_launch_column(hipStream_t stream, const AmtParams<T> &p)
     q.t_1 += shift; q.ft += shift; q.mu_tend += shift; q.msfuy += shift;
     q.msfvx_inv += shift; q.msftx += shift; q.msfty += shift;
     q.i0 -= (int)shift; q.i1 -= (int)shift;
-    const size_t lds = (size_t)(p.nk > 0 ? p.nk : 1) * 64 * sizeof(T);
+    const size_t lds = (size_t)(p.nk > 0 ? p.nk : 1) * 64 * sizeof(T);      // of ONE wave's dvdxi column
     // one dvdxi column per lane in LDS: 160 KB hold 320 levels in fp64, 640 in fp32 (the header's level limit)
     if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
-    const unsigned grid = (unsigned)((long)ntile_i * nj);
+    auto grid_for = [&](int rows) { return (unsigned)((long)ntile_i * ((nj + rows - 1) / rows)); };
     // tall columns: nothing in LDS, dvdxi evaluated twice (see the head of this file); AMT_COLUMN_RECOMPUTE=0|1 forces either
     const char *force = getenv("AMT_COLUMN_RECOMPUTE");          // read per launch: a test flips it in-process
     const bool recompute = force && *force ? atoi(force) != 0 : lds > 16 * 1024;
     if (recompute) {
-        hipLaunchKernelGGL((amt_column_kernel<T, true>), dim3(grid), dim3(64), 0, stream, q, ntile_i);
+        hipLaunchKernelGGL((amt_column_kernel<T, true>), dim3(grid_for(AMT_COLUMN_ROWS)), dim3(64 * AMT_COLUMN_ROWS), 0, stream, q, ntile_i);
         return hipGetLastError();
     }
-    if (lds > 64 * 1024) {
+    // the LDS flavour: as many rows per workgroup as fit 64 KB of dvdxi columns (one where a single column is larger: the forced
+    // AMT_COLUMN_RECOMPUTE=0 on tall columns)
+    int rows = AMT_COLUMN_ROWS;
+    while (rows > 1 && lds * rows > 64 * 1024) --rows;
+    if (lds * rows > 64 * 1024) {
         // beyond 64 KB of dynamic LDS a kernel has to be allowed to (per device, once)
         static unsigned granted = 0;
         int dev = 0;
@@ -158,7 +169,7 @@ hipError_t amt_launch_column(hipStream_t stream, const AmtParams<T> &p)
             granted |= 1u << (dev & 31);
         }
     }
-    hipLaunchKernelGGL((amt_column_kernel<T, false>), dim3(grid), dim3(64), lds, stream, q, ntile_i);
+    hipLaunchKernelGGL((amt_column_kernel<T, false>), dim3(grid_for(rows)), dim3(64 * rows), lds * rows, stream, q, ntile_i);
     return hipGetLastError();
 }
 
