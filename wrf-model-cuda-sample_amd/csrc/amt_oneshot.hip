@@ -962,13 +962,18 @@ struct Fan {
         if (rc == AMT_OK) rc = host_release_local();           // what the calling thread's own device copies hold comes down: the slots read the host arrays
         if (rc != AMT_OK) return rc;
         const HostWorkspace::Kept &mine = tl_workspace.res;    // the calling thread's settings go to every slot
-        for (int q = 0; q < n; ++q) {
-            std::unique_ptr<FanWorker> w(new (std::nothrow) FanWorker);
-            if (!w) { (void)stop(); return amt_fail(AMT_ERR_ALLOC, "host allocation failed"); }
-            w->device = ids[q];
-            FanWorker *raw = w.get();
-            w->th = std::thread([raw] { raw->main(); });
-            slots.push_back(std::move(w));
+        try {                                                  // std::thread and the containers throw; nothing may leave through the C-ABI
+            for (int q = 0; q < n; ++q) {
+                std::unique_ptr<FanWorker> w(new FanWorker);
+                w->device = ids[q];
+                FanWorker *raw = w.get();
+                slots.push_back(std::move(w));
+                slots.back()->th = std::thread([raw] { raw->main(); });
+            }
+        } catch (const std::exception &e) {
+            if (!slots.empty() && !slots.back()->th.joinable()) slots.pop_back();      // the slot whose thread did not start
+            (void)stop();
+            return amt_fail(AMT_ERR_ALLOC, "amt_host_set_devices: could not start %d slot threads: %s", n, e.what());
         }
         const bool enabled = mine.enabled, check = mine.check, defer_all = mine.defer_all;
         std::vector<const void *> deferred(mine.defer_ptr, mine.defer_ptr + mine.ndefer);
