@@ -454,7 +454,7 @@ static int amt_host_call(const AmtArgs<T> &h)
     const int nset = nchunk > 1 ? 2 : 1;
     const size_t crow = (size_t)rows + 2;                     // device rows per 3-D buffer set
     const size_t wrow = (size_t)nj + 2;                       // device rows of a 2-D array: the window's +-1
-    const bool threaded = may_thread && nchunk > 1;
+    bool threaded = may_thread && nchunk > 1;
 
     // packing (see above): the small arrays when they are pageable, the 3-D ones too when they
     // are pageable, one chunk and small
@@ -675,7 +675,7 @@ static int amt_host_call(const AmtArgs<T> &h)
             if (th.joinable()) th.join();
         }
     } dl;
-    if (threaded) {
+    if (threaded) try {
         dl.th = std::thread([&, device] {
             hipError_t e = hipSetDevice(device);
             for (int c = 0; c < nchunk; ++c) {
@@ -694,6 +694,8 @@ static int amt_host_call(const AmtArgs<T> &h)
                 dl.cv.notify_all();
             }
         });
+    } catch (const std::exception &) {
+        threaded = false;                                     // no thread to be had: the downloads are queued from this one (the pageable order)
     }
 
     // ---- the chunks -----------------------------------------------------------------------------
