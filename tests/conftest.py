@@ -42,7 +42,6 @@ def entry():
 @pytest.fixture(scope="session")
 def pkg(entry):
     """The product package (HIP library behind the C-ABI).  Built on demand."""
-    from pathlib import Path as _P
     p = entry.PKG_DIR / "libamt_advance_mu_t.so"
     if not p.exists():
         entry.build()

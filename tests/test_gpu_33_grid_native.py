@@ -3,10 +3,8 @@ halo columns of u, u_1, t_1, muu, msfuy (the i+1 / i-1 reads of module_small_ste
 one exchange for both, interior beside it.  (a) one rank as its own neighbour on all four sides (loopback: RCCL and IPC) against
 the ORACLE on the same arrays with the halo rows and columns copied by hand; (b) 2 x 2 and 3 x 2 real processes on cuda:0 over
 the IPC transport, NaN-poisoned halos, against the UNSPLIT oracle run."""
-import ctypes
 import os
 import subprocess
-import sys
 from pathlib import Path
 
 import numpy as np

@@ -7,8 +7,6 @@ import struct
 import threading
 import time
 
-import pytest
-
 MAGIC = b"AMTUID02"
 
 

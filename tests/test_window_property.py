@@ -1,6 +1,5 @@
 """Host logic without a GPU: the compute window (module_small_step_em.f90:91-106) as exported by the
 C-ABI against a direct Python restatement, and the j-slab split, on random bounds."""
-import numpy as np
 from hypothesis import given, settings, strategies as st
 
 
