@@ -27,7 +27,8 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "liboracle_amt.so"
+# AMT_ORACLE_LIBRARY: another build of the same checker (oracle/Makefile `san`: AddressSanitizer + UBSan)
+LIB_PATH = Path(os.environ.get("AMT_ORACLE_LIBRARY") or HERE / "liboracle_amt.so")
 REF_PATHS = {4: HERE / "_ref" / "libref_amt_f32.so", 8: HERE / "_ref" / "libref_amt_f64.so"}
 # timing only: the reference with its five debug dumps cut out (oracle/Makefile, target ref)
 REF_NODUMP_PATHS = {4: HERE / "_ref" / "libref_nodump_f32.so", 8: HERE / "_ref" / "libref_nodump_f64.so"}
