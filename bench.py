@@ -611,6 +611,9 @@ def self_launch(a):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     nonce = f"{os.getpid()}-{time.time_ns()}"
+    import shutil
+    import tempfile
+    launch_dir = tempfile.mkdtemp(prefix="amt_bench_")       # the rungs' rendezvous files: removed below however the ranks end
     procs, pumps = [], []
 
     def teardown(sig=signal.SIGKILL):
@@ -638,7 +641,7 @@ def self_launch(a):
         for r in range(a.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
                        LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                       AMT_RENDEZVOUS_NONCE=nonce, AMT_BENCH_SELF_LAUNCHED="1")
+                       AMT_RENDEZVOUS_NONCE=nonce, AMT_BENCH_SELF_LAUNCHED="1", AMT_BENCH_LAUNCH_DIR=launch_dir)
             if env.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":     # unset, or the image's quiet default
                 env["NCCL_DEBUG"] = "WARN"
             # the ranks run the script this process was started as (bench.py; or the test shim that injects --cpu-dry-run's compute)
@@ -682,6 +685,7 @@ def self_launch(a):
             t.join(timeout=2)
         for sg, h in old.items():
             signal.signal(sg, h)
+        shutil.rmtree(launch_dir, ignore_errors=True)
     return rc
 
 
@@ -1521,7 +1525,12 @@ def supervise(a):
                             timeout=datetime.timedelta(seconds=max(120.0, 2 * a.rung_timeout + 60.0)))   # never the 30-minute default
     shared = [None]
     if rank == 0:
-        shared[0] = {"dir": tempfile.mkdtemp(prefix="amt_bench_"), "nonce": f"{os.getpid()}-{time.time_ns()}"}
+        given = os.environ.get("AMT_BENCH_LAUNCH_DIR")           # self_launch owns (and removes) the directory; under another launcher rank 0 does
+        shared[0] = {"dir": given if given and os.path.isdir(given) else tempfile.mkdtemp(prefix="amt_bench_"),
+                     "nonce": f"{os.getpid()}-{time.time_ns()}"}
+        if shared[0]["dir"] != given:
+            import atexit
+            atexit.register(shutil.rmtree, shared[0]["dir"], ignore_errors=True)  # also when a rung or the group raises
     dist.broadcast_object_list(shared, src=0)
     launch_dir, nonce = shared[0]["dir"], shared[0]["nonce"]
     env = dict(os.environ, AMT_BENCH_DIR=launch_dir, AMT_RENDEZVOUS_NONCE=nonce)
